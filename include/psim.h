@@ -1,0 +1,266 @@
+/*
+ * psim.h -- C ABI of the MI355X (gfx950) particle-update backend.
+ *
+ * This is the boundary a host program binds to replace the reference's
+ * `trait ParticleSimulation` (reference: src/simulation/mod.rs:21-50) for the
+ * per-frame particle update.  Every entry point is `extern "C"`, takes plain
+ * pointers / integers only, returns a status code (0 = OK) and never throws or
+ * aborts.  A handle is NOT thread-safe: one host thread drives one handle, which
+ * is the reference's calling model (the UI thread, src/app.rs:306).
+ *
+ * Device layout: structure-of-arrays.  Six fp32 arrays px,py,pz,vx,vy,vz hold the
+ * live physics state (24 B/particle); colour (RGBA), initial colour (RGBA) and the
+ * two padding floats of the reference's 64-byte record live in side arrays that
+ * the update kernel touches only when color_mode is 1 or 2.  The reference's
+ * 64-byte AoS `Particle` is the import/export format (psim_upload_aos /
+ * psim_download_aos).
+ */
+#ifndef PSIM_H
+#define PSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- plain-old-data records shared with the reference --------------------- */
+
+/* Field-for-field the reference's `#[repr(C)] struct SimParams`
+ * (src/simulation/mod.rs:52-67); 48 bytes, align 4. */
+typedef struct psim_sim_params {
+    float    delta_time;          /* @0  */
+    float    gravity;             /* @4  */
+    uint32_t color_mode;          /* @8   0 keep colour, 1 speed, 2 distance */
+    float    mouse_force;         /* @12 */
+    float    mouse_radius;        /* @16 */
+    uint32_t is_mouse_dragging;   /* @20  attractor active when > 0 */
+    float    damping;             /* @24 */
+    float    max_dist_for_color;  /* @28 */
+    float    mouse_position[3];   /* @32  attractor position */
+    uint32_t _padding2;           /* @44 */
+} psim_sim_params;
+
+/* Field-for-field the reference's `#[repr(C)] struct Particle`
+ * (src/simulation/mod.rs:86-98); 64 bytes. */
+typedef struct psim_particle {
+    float position[3];       /* @0  */
+    float padding1;          /* @12 */
+    float velocity[3];       /* @16 */
+    float padding2;          /* @28 */
+    float color[4];          /* @32 */
+    float initial_color[4];  /* @48 */
+} psim_particle;
+
+/* One attractor of the multi-attractor extension (no counterpart in the
+ * reference, which has exactly one attractor: the mouse_* fields of SimParams,
+ * src/simulation/mod.rs:58-65).  With one active attractor whose fields equal
+ * mouse_position / mouse_force / mouse_radius the result is identical to
+ * psim_update.  32 bytes. */
+typedef struct psim_attractor {
+    float    position[3];  /* @0  */
+    float    force;        /* @12 */
+    float    radius;       /* @16 */
+    uint32_t active;       /* @20  applied when > 0 */
+    uint32_t _pad[2];      /* @24 */
+} psim_attractor;
+
+#define PSIM_MAX_ATTRACTORS 64u
+
+/* Raw device pointers of a handle's SoA storage (valid until the next
+ * psim_resize / psim_destroy).  Replaces `get_particle_buffer`
+ * (src/simulation/mod.rs:44) for consumers that read device memory directly. */
+typedef struct psim_soa_view {
+    float *px, *py, *pz;     /* count floats each */
+    float *vx, *vy, *vz;     /* count floats each */
+    float *color;            /* 4*count floats, RGBA interleaved */
+    float *initial_color;    /* 4*count floats, RGBA interleaved */
+    float *padding;          /* 2*count floats: {padding1, padding2} */
+    uint32_t count;          /* active particles */
+    uint32_t capacity;       /* allocated particles (>= count) */
+} psim_soa_view;
+
+typedef struct psim_handle psim_handle;
+
+/* ---- enums ---------------------------------------------------------------- */
+
+/* Status codes.  psim_last_error() holds the text of the most recent failure on
+ * the calling thread. */
+enum {
+    PSIM_OK            = 0,
+    PSIM_ERR_INVALID   = 1,   /* bad argument (null, out of range, misaligned) */
+    PSIM_ERR_HIP       = 2,   /* a HIP runtime call failed */
+    PSIM_ERR_NOMEM     = 3,   /* device or host allocation failed */
+    PSIM_ERR_NO_DEVICE = 4    /* no usable gfx950 device */
+};
+
+/* `enum SphereGeneration` (src/simulation/mod.rs:15-19) plus the synthetic
+ * benchmark distribution. */
+enum {
+    PSIM_GEN_HOLLOW  = 0,  /* Fibonacci sphere, r = 50 (mod.rs:150-167) */
+    PSIM_GEN_FILLED  = 1,  /* seeded uniform ball, r = 50 (mod.rs:168-188) */
+    PSIM_GEN_UNIFORM = 2   /* positions U[-50,50)^3, velocities U[-1,1)^3,
+                              counter-based SplitMix64, seed 69 (generated on the
+                              device; index-addressed so shards are reproducible) */
+};
+
+/* `enum SimulationMethod` (src/simulation/mod.rs:9-13) plus this backend. */
+enum {
+    PSIM_METHOD_CPU            = 0,
+    PSIM_METHOD_COMPUTE_SHADER = 1,
+    PSIM_METHOD_HIP            = 2
+};
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* Replaces `ParticleSimulation::new` (src/simulation/mod.rs:22-29; call sites
+ * src/app.rs:106-125, 182-195).  The wgpu device / surface-format arguments are
+ * dropped; `device_id` selects the GPU.  Allocates SoA storage for `count`
+ * particles, fills it with `generation_mode`, creates the handle's stream. */
+int psim_create(psim_handle **out, uint32_t count, int generation_mode, int device_id);
+
+/* Same, for one shard of a larger particle array that is partitioned across
+ * GPUs: this handle owns global particles [global_first, global_first + count)
+ * of `global_count`.  Generators address particles by global index, so the union
+ * of the shards equals the single-GPU array.  No counterpart in the reference
+ * (single device). */
+int psim_create_shard(psim_handle **out, uint32_t count, uint64_t global_first,
+                      uint64_t global_count, int generation_mode, int device_id);
+
+/* Drop of the simulation object. */
+void psim_destroy(psim_handle *h);
+
+/* ---- the hot path --------------------------------------------------------- */
+
+/* Replaces `ParticleSimulation::update` (src/simulation/mod.rs:30-36; call site
+ * src/app.rs:306-307).  One semi-implicit Euler step for all active particles
+ * with the arithmetic of src/simulation/cpu.rs:65-113.  Asynchronous like the
+ * reference's compute backend (src/simulation/compute.rs:124-144): the kernel is
+ * enqueued on the handle's stream and the call returns; `*params` is copied
+ * before returning.  Like the reference, the paused flag is NOT consulted here
+ * (the caller gates on is_paused, src/app.rs:283). */
+int psim_update(psim_handle *h, const psim_sim_params *params);
+
+/* Multi-attractor step: gravity, then for a = 0..n_attractors-1 in index order
+ * the reference's force law (src/simulation/cpu.rs:76-83) with attractor a's
+ * position / force / radius, then integrate / damp / colour as psim_update.
+ * `attractors_device` is DEVICE memory (e.g. the receive buffer of an RCCL
+ * all-gather enqueued earlier on the same stream); it is read when the kernel
+ * runs.  The mouse_* fields and is_mouse_dragging of `params` are ignored.
+ * n_attractors <= PSIM_MAX_ATTRACTORS. */
+int psim_update_multi(psim_handle *h, const psim_sim_params *params,
+                      const psim_attractor *attractors_device, uint32_t n_attractors);
+
+/* Same with the attractor list in HOST memory: copied by value into the launch,
+ * no device buffer or synchronisation needed.  n_attractors <= 8. */
+int psim_update_multi_host(psim_handle *h, const psim_sim_params *params,
+                           const psim_attractor *attractors_host, uint32_t n_attractors);
+
+/* Stateless form of psim_update over caller-owned device arrays (each `count`
+ * floats; `color` may be null when params->color_mode is 0, else 4*count
+ * floats), enqueued on `hip_stream` (null = the default stream) of the current
+ * device.  For callers that keep particle state in their own allocations. */
+int psim_update_soa(float *px, float *py, float *pz, float *vx, float *vy, float *vz,
+                    float *color, uint32_t count, const psim_sim_params *params,
+                    void *hip_stream);
+
+/* Writes one attractor record into device memory at `dst_device` from a host
+ * value, asynchronously on the handle's stream (the value travels in the kernel
+ * arguments, so the host copy may be reused immediately).  Used to stage this
+ * rank's attractor into the send buffer of the all-gather. */
+int psim_store_attractor(psim_handle *h, psim_attractor *dst_device,
+                         const psim_attractor *value_host);
+
+/* Blocks until everything enqueued on the handle's stream has finished.  The
+ * reference's equivalent is the caller's queue.submit + present (src/app.rs:313). */
+int psim_sync(psim_handle *h);
+
+/* ---- state management ----------------------------------------------------- */
+
+/* Replaces `resize_buffer` (src/simulation/mod.rs:37-43; call site
+ * src/app.rs:479-491) with the compute backend's semantics
+ * (src/simulation/compute.rs:146-193): records the generation mode; no-op when
+ * new_count equals the current count; otherwise regenerates ALL particles for
+ * new_count (state is lost); storage grows when needed and is kept on shrink. */
+int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode);
+
+/* Replaces `reset` (src/simulation/mod.rs:47; call site src/app.rs:336-343):
+ * regenerates the current count of particles with `generation_mode`. */
+int psim_reset(psim_handle *h, int generation_mode);
+
+/* `get_particle_count` (src/simulation/mod.rs:46). */
+uint32_t psim_particle_count(const psim_handle *h);
+
+/* `get_method` (src/simulation/mod.rs:45); always PSIM_METHOD_HIP. */
+int psim_method(const psim_handle *h);
+
+/* `is_paused` / `set_paused` (src/simulation/mod.rs:48-49): a plain flag the
+ * caller honours. */
+int  psim_is_paused(const psim_handle *h);
+void psim_set_paused(psim_handle *h, int paused);
+
+/* ---- particle data in and out (replaces `get_particle_buffer`,
+ *      src/simulation/mod.rs:44, whose consumer is the renderer's 64-byte
+ *      instance layout, src/renderer.rs:32-67) ------------------------------- */
+
+/* Copies particles [first, first+n) to / from HOST memory in the reference's
+ * 64-byte AoS layout (transposed on the device).  Synchronous. */
+int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n);
+int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint64_t first, uint64_t n);
+
+/* Copies positions and velocities of particles [first, first+n) to / from HOST
+ * memory as six consecutive arrays of n floats: px | py | pz | vx | vy | vz.
+ * Synchronous. */
+int psim_download_soa(psim_handle *h, float *dst_host, uint64_t first, uint64_t n);
+int psim_upload_soa(psim_handle *h, const float *src_host, uint64_t first, uint64_t n);
+
+/* Transposes particles [first, first+n) into / out of a DEVICE buffer in the
+ * 64-byte AoS layout (e.g. a vertex buffer shared with a renderer), on the
+ * handle's stream, asynchronously. */
+int psim_export_aos_device(psim_handle *h, psim_particle *dst_device, uint64_t first, uint64_t n);
+int psim_import_aos_device(psim_handle *h, const psim_particle *src_device, uint64_t first, uint64_t n);
+
+/* Raw SoA device pointers. */
+int psim_device_soa(psim_handle *h, psim_soa_view *view);
+
+/* Order-independent checksums of the active state, computed on the device with
+ * wavefront reductions: out[k] = sum over particles of the uint32 bit pattern of
+ * component k (k = 0..5 : px,py,pz,vx,vy,vz) as a uint64 (mod 2^64).
+ * Synchronous.  No counterpart in the reference; lets a caller verify a
+ * multi-gigabyte state without downloading it. */
+int psim_checksum(psim_handle *h, uint64_t out[6]);
+
+/* ---- streams -------------------------------------------------------------- */
+
+/* Makes the handle enqueue on a caller-owned hipStream_t (e.g. the stream an
+ * RCCL collective is ordered on).  Null restores the handle's own stream. */
+int   psim_set_stream(psim_handle *h, void *hip_stream);
+void *psim_get_stream(const psim_handle *h);
+
+/* Device ordinal the handle lives on. */
+int psim_device(const psim_handle *h);
+
+/* ---- timing ---------------------------------------------------------------- */
+
+/* Device-side timer around work enqueued on the handle's stream.  The reference
+ * times `update` with a host wall clock (src/app.rs:303-315), which for its GPU
+ * backend measures command encoding only; because psim_update is asynchronous the
+ * equivalent here is a pair of stream events.  psim_timer_start records the start
+ * event; psim_timer_stop records the stop event, waits for it and returns the
+ * milliseconds the stream spent between the two. */
+int psim_timer_start(psim_handle *h);
+int psim_timer_stop(psim_handle *h, float *elapsed_ms);
+
+/* ---- errors --------------------------------------------------------------- */
+
+/* Text of the most recent failure on the calling thread ("" if none). */
+const char *psim_last_error(void);
+
+/* Library version string. */
+const char *psim_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PSIM_H */

@@ -1,0 +1,359 @@
+"""MI355X (gfx950) backend for the particle-update path of particle-simulation-3d.
+
+This package is a thin ctypes binding over ``csrc/libpsim_hip.so`` (the C ABI of
+``include/psim.h``) plus :class:`HipParticleSimulation`, a host-side mirror of the
+reference's ``trait ParticleSimulation`` (reference: src/simulation/mod.rs:21-50)
+with the wgpu arguments dropped.  All particle arithmetic runs in hand-written HIP
+kernels; there is no CPU fallback, and a missing library is an error.
+
+The directory name contains hyphens, so import it with
+``importlib.import_module("particle-simulation-3d_amd")``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "csrc", "libpsim_hip.so")
+
+# ---- records shared with the reference ---------------------------------------
+
+# `#[repr(C)] struct Particle`, 64 bytes (reference: src/simulation/mod.rs:86-98).
+PARTICLE_DTYPE = np.dtype(
+    [
+        ("position", "<f4", (3,)),
+        ("padding1", "<f4"),
+        ("velocity", "<f4", (3,)),
+        ("padding2", "<f4"),
+        ("color", "<f4", (4,)),
+        ("initial_color", "<f4", (4,)),
+    ]
+)
+assert PARTICLE_DTYPE.itemsize == 64
+
+# One attractor of the multi-attractor extension, 32 bytes (include/psim.h).
+ATTRACTOR_DTYPE = np.dtype(
+    [
+        ("position", "<f4", (3,)),
+        ("force", "<f4"),
+        ("radius", "<f4"),
+        ("active", "<u4"),
+        ("_pad", "<u4", (2,)),
+    ]
+)
+assert ATTRACTOR_DTYPE.itemsize == 32
+
+
+class SimParams(ctypes.Structure):
+    """`#[repr(C)] struct SimParams`, 48 bytes (reference: src/simulation/mod.rs:52-67).
+
+    The defaults are `impl Default for SimParams` (mod.rs:69-84).
+    """
+
+    _fields_ = [
+        ("delta_time", c_float),
+        ("gravity", c_float),
+        ("color_mode", c_uint32),
+        ("mouse_force", c_float),
+        ("mouse_radius", c_float),
+        ("is_mouse_dragging", c_uint32),
+        ("damping", c_float),
+        ("max_dist_for_color", c_float),
+        ("mouse_position", c_float * 3),
+        ("_padding2", c_uint32),
+    ]
+
+    def __init__(self, delta_time=0.016, gravity=0.0, color_mode=0, mouse_force=5.0,
+                 mouse_radius=10.0, is_mouse_dragging=0, damping=0.99,
+                 max_dist_for_color=50.0, mouse_position=(0.0, 0.0, 0.0)):
+        super().__init__()
+        self.delta_time = delta_time
+        self.gravity = gravity
+        self.color_mode = color_mode
+        self.mouse_force = mouse_force
+        self.mouse_radius = mouse_radius
+        self.is_mouse_dragging = is_mouse_dragging
+        self.damping = damping
+        self.max_dist_for_color = max_dist_for_color
+        self.mouse_position = (c_float * 3)(*mouse_position)
+        self._padding2 = 0
+
+
+assert ctypes.sizeof(SimParams) == 48
+
+
+class SoaView(ctypes.Structure):
+    """`psim_soa_view`: raw device pointers of a handle's storage."""
+
+    _fields_ = [(n, c_void_p) for n in
+                ("px", "py", "pz", "vx", "vy", "vz", "color", "initial_color", "padding")] + [
+        ("count", c_uint32), ("capacity", c_uint32)]
+
+
+# `enum SphereGeneration` (mod.rs:15-19) + the synthetic benchmark distribution.
+GEN_HOLLOW, GEN_FILLED, GEN_UNIFORM = 0, 1, 2
+# `enum SimulationMethod` (mod.rs:9-13) + this backend.
+METHOD_CPU, METHOD_COMPUTE_SHADER, METHOD_HIP = 0, 1, 2
+MAX_ATTRACTORS = 64
+MAX_HOST_ATTRACTORS = 8
+
+# Every symbol include/psim.h declares: name -> (restype, argtypes).
+_P = c_void_p
+ABI = {
+    "psim_create": (c_int, [POINTER(_P), c_uint32, c_int, c_int]),
+    "psim_create_shard": (c_int, [POINTER(_P), c_uint32, c_uint64, c_uint64, c_int, c_int]),
+    "psim_destroy": (None, [_P]),
+    "psim_update": (c_int, [_P, POINTER(SimParams)]),
+    "psim_update_multi": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
+    "psim_update_multi_host": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
+    "psim_update_soa": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_uint32, POINTER(SimParams), _P]),
+    "psim_store_attractor": (c_int, [_P, _P, _P]),
+    "psim_sync": (c_int, [_P]),
+    "psim_resize": (c_int, [_P, c_uint32, c_int]),
+    "psim_reset": (c_int, [_P, c_int]),
+    "psim_particle_count": (c_uint32, [_P]),
+    "psim_method": (c_int, [_P]),
+    "psim_is_paused": (c_int, [_P]),
+    "psim_set_paused": (None, [_P, c_int]),
+    "psim_download_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_upload_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_download_soa": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_upload_soa": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_export_aos_device": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_import_aos_device": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_device_soa": (c_int, [_P, POINTER(SoaView)]),
+    "psim_checksum": (c_int, [_P, POINTER(c_uint64)]),
+    "psim_set_stream": (c_int, [_P, _P]),
+    "psim_get_stream": (_P, [_P]),
+    "psim_device": (c_int, [_P]),
+    "psim_timer_start": (c_int, [_P]),
+    "psim_timer_stop": (c_int, [_P, POINTER(c_float)]),
+    "psim_last_error": (c_char_p, []),
+    "psim_version": (c_char_p, []),
+}
+
+_lib = None
+
+
+class PsimError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"psim error {code}: {message}")
+        self.code = code
+
+
+def load_library():
+    """Loads ``csrc/libpsim_hip.so`` and declares every entry point.
+
+    Raises ``RuntimeError`` if the library has not been built; nothing else can
+    compute the update.
+    """
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBRARY_PATH):
+        raise RuntimeError(
+            f"{LIBRARY_PATH} is missing: build it with `make -C {os.path.dirname(LIBRARY_PATH)}` "
+            "(or __graft_entry__.build()); this backend has no CPU fallback")
+    lib = ctypes.CDLL(LIBRARY_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in ABI.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PsimError(rc, load_library().psim_last_error().decode())
+
+
+def _as_attractors(attractors):
+    arr = np.ascontiguousarray(attractors, dtype=ATTRACTOR_DTYPE)
+    return arr
+
+
+class HipParticleSimulation:
+    """Host-side mirror of the reference's ``trait ParticleSimulation``
+    (src/simulation/mod.rs:21-50) over the C ABI.
+
+    Method names and argument meaning follow the trait; the wgpu device / queue /
+    encoder / surface-format arguments are dropped.  ``update`` is asynchronous,
+    as in the reference's compute backend (src/simulation/compute.rs:124-144);
+    call :meth:`sync` (or any download) to wait.
+    """
+
+    def __init__(self, handle):
+        self._h = handle
+        self._lib = load_library()
+
+    # -- `fn new(device, initial_particle_count, surface_format, generation_mode)`
+    @classmethod
+    def new(cls, initial_particle_count, generation_mode=GEN_HOLLOW, device_id=0):
+        lib = load_library()
+        h = c_void_p()
+        _check(lib.psim_create(byref(h), initial_particle_count, generation_mode, device_id))
+        return cls(h)
+
+    @classmethod
+    def new_shard(cls, count, global_first, global_count, generation_mode=GEN_UNIFORM,
+                  device_id=0):
+        """One shard [global_first, global_first + count) of a `global_count` set."""
+        lib = load_library()
+        h = c_void_p()
+        _check(lib.psim_create_shard(byref(h), count, global_first, global_count,
+                                     generation_mode, device_id))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            self._lib.psim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- `fn update(&mut self, device, queue, encoder, params: &SimParams)`
+    def update(self, params):
+        _check(self._lib.psim_update(self._h, byref(params)))
+
+    def update_multi_device(self, params, attractors_device_ptr, n_attractors):
+        """Multi-attractor step with the list in DEVICE memory (integer address)."""
+        _check(self._lib.psim_update_multi(self._h, byref(params),
+                                           c_void_p(attractors_device_ptr), n_attractors))
+
+    def update_multi(self, params, attractors):
+        """Multi-attractor step with a host list (ATTRACTOR_DTYPE array, <= 8)."""
+        arr = _as_attractors(attractors)
+        _check(self._lib.psim_update_multi_host(self._h, byref(params),
+                                                arr.ctypes.data_as(c_void_p), len(arr)))
+
+    def store_attractor(self, dst_device_ptr, attractor):
+        arr = _as_attractors(attractor).reshape(-1)[:1]
+        _check(self._lib.psim_store_attractor(self._h, c_void_p(dst_device_ptr),
+                                              arr.ctypes.data_as(c_void_p)))
+
+    def sync(self):
+        _check(self._lib.psim_sync(self._h))
+
+    # -- `fn resize_buffer(&mut self, device, queue, new_count, generation_mode)`
+    def resize_buffer(self, new_count, generation_mode):
+        _check(self._lib.psim_resize(self._h, new_count, generation_mode))
+
+    # -- `fn get_method(&self) -> SimulationMethod`
+    def get_method(self):
+        return self._lib.psim_method(self._h)
+
+    # -- `fn get_particle_count(&self) -> u32`
+    def get_particle_count(self):
+        return self._lib.psim_particle_count(self._h)
+
+    # -- `fn reset(&mut self, device, queue, generation_mode)`
+    def reset(self, generation_mode):
+        _check(self._lib.psim_reset(self._h, generation_mode))
+
+    # -- `fn is_paused(&self) -> bool` / `fn set_paused(&mut self, paused: bool)`
+    def is_paused(self):
+        return bool(self._lib.psim_is_paused(self._h))
+
+    def set_paused(self, paused):
+        self._lib.psim_set_paused(self._h, 1 if paused else 0)
+
+    # -- `fn get_particle_buffer(&self) -> &wgpu::Buffer`: the device pointers
+    def get_particle_buffer(self):
+        view = SoaView()
+        _check(self._lib.psim_device_soa(self._h, byref(view)))
+        return view
+
+    # -- particle data in and out
+    def download_aos(self, first=0, n=None):
+        n = self.get_particle_count() - first if n is None else n
+        out = np.empty(n, dtype=PARTICLE_DTYPE)
+        _check(self._lib.psim_download_aos(self._h, out.ctypes.data_as(c_void_p), first, n))
+        return out
+
+    def upload_aos(self, particles, first=0):
+        arr = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
+        _check(self._lib.psim_upload_aos(self._h, arr.ctypes.data_as(c_void_p), first, len(arr)))
+
+    def download_soa(self, first=0, n=None):
+        """Returns a (6, n) float32 array: px, py, pz, vx, vy, vz."""
+        n = self.get_particle_count() - first if n is None else n
+        out = np.empty((6, n), dtype=np.float32)
+        _check(self._lib.psim_download_soa(self._h, out.ctypes.data_as(c_void_p), first, n))
+        return out
+
+    def upload_soa(self, soa, first=0):
+        arr = np.ascontiguousarray(soa, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[0] != 6:
+            raise ValueError("expected a (6, n) float32 array")
+        _check(self._lib.psim_upload_soa(self._h, arr.ctypes.data_as(c_void_p), first,
+                                         arr.shape[1]))
+
+    def export_aos_device(self, dst_device_ptr, first=0, n=None):
+        n = self.get_particle_count() - first if n is None else n
+        _check(self._lib.psim_export_aos_device(self._h, c_void_p(dst_device_ptr), first, n))
+
+    def import_aos_device(self, src_device_ptr, first=0, n=None):
+        n = self.get_particle_count() - first if n is None else n
+        _check(self._lib.psim_import_aos_device(self._h, c_void_p(src_device_ptr), first, n))
+
+    def checksum(self):
+        out = (c_uint64 * 6)()
+        _check(self._lib.psim_checksum(self._h, out))
+        return [int(v) for v in out]
+
+    # -- streams
+    def set_stream(self, hip_stream_ptr):
+        _check(self._lib.psim_set_stream(self._h, c_void_p(hip_stream_ptr)))
+
+    def get_stream(self):
+        return self._lib.psim_get_stream(self._h)
+
+    def device(self):
+        return self._lib.psim_device(self._h)
+
+    # -- device timer around enqueued work
+    def timer_start(self):
+        _check(self._lib.psim_timer_start(self._h))
+
+    def timer_stop(self):
+        """Waits for the enqueued work and returns the device milliseconds."""
+        ms = c_float()
+        _check(self._lib.psim_timer_stop(self._h, byref(ms)))
+        return float(ms.value)
+
+    @property
+    def handle(self):
+        return self._h
+
+
+def update_soa(px, py, pz, vx, vy, vz, color, count, params, stream=0):
+    """Stateless update over caller-owned DEVICE arrays (integer addresses)."""
+    lib = load_library()
+    _check(lib.psim_update_soa(c_void_p(px), c_void_p(py), c_void_p(pz), c_void_p(vx),
+                               c_void_p(vy), c_void_p(vz), c_void_p(color), count,
+                               byref(params), c_void_p(stream)))
+
+
+def version():
+    return load_library().psim_version().decode()
+
+
+sys.modules.setdefault("psim_amd", sys.modules[__name__])

@@ -1,0 +1,673 @@
+// psim_api.hip -- the extern "C" boundary declared in include/psim.h.
+//
+// A handle owns one device allocation carved into the SoA arrays, one stream and
+// a small staging buffer.  All entry points return status codes; nothing throws
+// across the boundary.  There is no CPU fallback: without a gfx950 device
+// psim_create fails with PSIM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "psim_kernels.h"
+
+static_assert(sizeof(psim_sim_params) == 48, "SimParams is 48 bytes (mod.rs:52-67)");
+static_assert(offsetof(psim_sim_params, color_mode) == 8, "layout");
+static_assert(offsetof(psim_sim_params, is_mouse_dragging) == 20, "layout");
+static_assert(offsetof(psim_sim_params, mouse_position) == 32, "layout");
+static_assert(sizeof(psim_particle) == 64, "Particle is 64 bytes (mod.rs:86-98)");
+static_assert(offsetof(psim_particle, velocity) == 16, "layout");
+static_assert(offsetof(psim_particle, color) == 32, "layout");
+static_assert(offsetof(psim_particle, initial_color) == 48, "layout");
+static_assert(sizeof(psim_attractor) == 32, "attractor record is 32 bytes");
+
+#define PSIM_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? PSIM_ERR_NOMEM : PSIM_ERR_HIP,      \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                      \
+    } while (0)
+
+constexpr uint64_t kUniformSeed = 69;          // the reference's own seed, mod.rs:170
+constexpr uint32_t kStageParticles = 1u << 22; // AoS staging chunk: 4 Mi particles = 256 MiB
+constexpr uint32_t kCapacityQuantum = 1024;    // particles; keeps every array 4 KiB-granular
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+}  // namespace
+
+struct psim_handle {
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t count = 0;
+    uint32_t capacity = 0;
+    uint64_t global_first = 0;
+    uint64_t global_count = 0;   // 0 = not a shard: the set is [0, count)
+    int generation_mode = PSIM_GEN_HOLLOW;
+    bool paused = false;
+    void *slab = nullptr;        // one allocation, carved into `soa`
+    psim::SoaPtrs soa = {};
+    uint64_t *checksum_dev = nullptr;          // 8 x u64 inside the slab
+    psim_attractor *attr_stage_dev = nullptr;  // PSIM_MAX_ATTRACTORS records inside the slab
+    psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    psim::LaunchTuning tuning = {0, 1, 1};
+};
+
+namespace {
+
+uint32_t round_capacity(uint32_t n)
+{
+    uint64_t c = ((uint64_t)n + kCapacityQuantum - 1) / kCapacityQuantum * kCapacityQuantum;
+    if (c == 0) c = kCapacityQuantum;
+    if (c > 0xFFFFFC00ull) c = 0xFFFFFC00ull;
+    return (uint32_t)c;
+}
+
+// Carves the slab: six fp32 arrays, colour, initial colour, padding, scratch.
+// `skew` extra bytes separate consecutive fp32 arrays so that the six streams do
+// not sit at the same offset modulo the memory-channel interleave.
+int allocate(psim_handle *h, uint32_t capacity)
+{
+    const uint64_t cap = capacity;
+    const uint64_t skew = (uint64_t)env_int("PSIM_SKEW_BYTES", 0) & ~255ull;
+    const uint64_t f32_bytes = cap * 4 + skew;
+    const uint64_t total = 6 * f32_bytes + cap * 16 * 2 + cap * 8 + 4096;
+    void *slab = nullptr;
+    HIP_TRY(hipMalloc(&slab, total));
+    char *b = static_cast<char *>(slab);
+    h->slab = slab;
+    h->soa.px = reinterpret_cast<float *>(b + 0 * f32_bytes);
+    h->soa.py = reinterpret_cast<float *>(b + 1 * f32_bytes);
+    h->soa.pz = reinterpret_cast<float *>(b + 2 * f32_bytes);
+    h->soa.vx = reinterpret_cast<float *>(b + 3 * f32_bytes);
+    h->soa.vy = reinterpret_cast<float *>(b + 4 * f32_bytes);
+    h->soa.vz = reinterpret_cast<float *>(b + 5 * f32_bytes);
+    b += 6 * f32_bytes;
+    h->soa.color = reinterpret_cast<float *>(b);
+    b += cap * 16;
+    h->soa.initial_color = reinterpret_cast<float *>(b);
+    b += cap * 16;
+    h->soa.padding = reinterpret_cast<float *>(b);
+    b += cap * 8;
+    h->checksum_dev = reinterpret_cast<uint64_t *>(b);
+    h->attr_stage_dev = reinterpret_cast<psim_attractor *>(b + 256);
+    h->capacity = capacity;
+    return PSIM_OK;
+}
+
+int ensure_stage(psim_handle *h)
+{
+    if (h->aos_stage) return PSIM_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->aos_stage),
+                      (size_t)kStageParticles * sizeof(psim_particle)));
+    return PSIM_OK;
+}
+
+// ---- the reference's generators, on the host --------------------------------
+// cos/sin/cbrt/acos of fp32 arguments differ between a device math library and
+// the host C library the reference's Rust std calls, so these two initial states
+// are produced on the host and uploaded.  They run at creation / reset only.
+
+// Fibonacci sphere, src/simulation/mod.rs:150-167.  `count` is the size of the
+// whole set; particles [first, first + n) are written.
+void gen_hollow(psim_particle *out, uint32_t count, uint64_t first, uint64_t n)
+{
+    const float radius = 50.0f;
+    const float golden = 3.14159265358979323846f * (3.0f - sqrtf(5.0f));
+    const float denom = (float)((count > 1u ? count : 1u) - 1u);
+    for (uint64_t k = 0; k < n; ++k) {
+        const float fi = (float)(uint32_t)(first + k);
+        const float y = 1.0f - (fi / denom) * 2.0f;
+        const float ring = sqrtf(1.0f - y * y);
+        const float theta = golden * fi;
+        const float x = cosf(theta) * ring;
+        const float z = sinf(theta) * ring;
+        psim_particle &q = out[k];
+        q.position[0] = x * radius;
+        q.position[1] = y * radius;
+        q.position[2] = z * radius;
+        q.padding1 = 0.0f;
+        q.velocity[0] = q.velocity[1] = q.velocity[2] = 0.0f;
+        q.padding2 = 0.0f;
+        for (int c = 0; c < 3; ++c)
+            q.color[c] = q.initial_color[c] = (q.position[c] / radius + 1.0f) * 0.5f;
+        q.color[3] = q.initial_color[3] = 1.0f;
+    }
+}
+
+// The generator behind the reference's `SmallRng::seed_from_u64(69)`
+// (src/simulation/mod.rs:170): Xoshiro256++ with SplitMix64 seeding; an f32 draw
+// is the top 24 bits of the upper half of a 64-bit output, times 2^-24.
+struct Xoshiro256pp {
+    uint64_t s[4];
+    explicit Xoshiro256pp(uint64_t seed)
+    {
+        for (auto &w : s) {
+            seed += 0x9E3779B97F4A7C15ull;
+            uint64_t z = seed;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            w = z ^ (z >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next()
+    {
+        const uint64_t r = rotl(s[0] + s[3], 23) + s[0];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return r;
+    }
+    float next_f32() { return (float)((uint32_t)(next() >> 32) >> 8) * 0x1.0p-24f; }
+};
+
+// Seeded uniform ball, src/simulation/mod.rs:168-188.  The stream is sequential:
+// `rng` must already stand at particle `first`.
+void gen_filled(psim_particle *out, Xoshiro256pp &rng, uint64_t n)
+{
+    const float radius = 50.0f;
+    const float pi = 3.14159265358979323846f;
+    for (uint64_t k = 0; k < n; ++k) {
+        const float r = radius * cbrtf(rng.next_f32());
+        const float theta = rng.next_f32() * 2.0f * pi;
+        const float phi = acosf(rng.next_f32() * 2.0f - 1.0f);
+        psim_particle &q = out[k];
+        q.position[0] = r * sinf(phi) * cosf(theta);
+        q.position[1] = r * cosf(phi);
+        q.position[2] = r * sinf(phi) * sinf(theta);
+        q.padding1 = 0.0f;
+        q.velocity[0] = q.velocity[1] = q.velocity[2] = 0.0f;
+        q.padding2 = 0.0f;
+        for (int c = 0; c < 3; ++c)
+            q.color[c] = q.initial_color[c] = (q.position[c] / radius + 1.0f) * 0.5f;
+        q.color[3] = q.initial_color[3] = 1.0f;
+    }
+}
+
+int upload_aos_chunked(psim_handle *h, const psim_particle *src, uint64_t first, uint64_t n);
+
+// Fills particles [0, count) of the handle with `mode`.
+int generate(psim_handle *h, int mode)
+{
+    const uint64_t gfirst = h->global_first;
+    const uint32_t gcount32 =
+        (uint32_t)(h->global_count ? h->global_count : (uint64_t)h->count);
+    if (mode == PSIM_GEN_UNIFORM) {
+        HIP_TRY(psim::launch_gen_uniform(h->soa, h->count, gfirst, kUniformSeed,
+                                         (uint32_t)h->num_cus * 16u, h->stream));
+        return PSIM_OK;
+    }
+    if (mode != PSIM_GEN_HOLLOW && mode != PSIM_GEN_FILLED)
+        return fail(PSIM_ERR_INVALID, "unknown generation mode %d", mode);
+    const uint64_t chunk = 1u << 20;
+    std::vector<psim_particle> host;
+    try {
+        host.resize((size_t)(h->count < chunk ? h->count : chunk));
+    } catch (const std::bad_alloc &) {
+        return fail(PSIM_ERR_NOMEM, "host allocation for the generator failed");
+    }
+    Xoshiro256pp rng(kUniformSeed);
+    if (mode == PSIM_GEN_FILLED)
+        for (uint64_t k = 0; k < 3 * gfirst; ++k) rng.next();   // skip earlier shards' draws
+    for (uint64_t done = 0; done < h->count; done += chunk) {
+        const uint64_t m = (h->count - done) < chunk ? (h->count - done) : chunk;
+        if (mode == PSIM_GEN_HOLLOW) gen_hollow(host.data(), gcount32, gfirst + done, m);
+        else gen_filled(host.data(), rng, m);
+        int rc = upload_aos_chunked(h, host.data(), done, m);
+        if (rc != PSIM_OK) return rc;
+    }
+    return PSIM_OK;
+}
+
+int upload_aos_chunked(psim_handle *h, const psim_particle *src, uint64_t first, uint64_t n)
+{
+    int rc = ensure_stage(h);
+    if (rc != PSIM_OK) return rc;
+    for (uint64_t done = 0; done < n; done += kStageParticles) {
+        const uint32_t m = (uint32_t)((n - done) < kStageParticles ? (n - done) : kStageParticles);
+        HIP_TRY(hipMemcpyAsync(h->aos_stage, src + done, (size_t)m * sizeof(psim_particle),
+                               hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)(first + done), m, h->aos_stage,
+                                        h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return PSIM_OK;
+}
+
+int check_range(const psim_handle *h, uint64_t first, uint64_t n)
+{
+    if (first > h->count || n > h->count - first)
+        return fail(PSIM_ERR_INVALID, "range [%llu, +%llu) exceeds particle count %u",
+                    (unsigned long long)first, (unsigned long long)n, h->count);
+    return PSIM_OK;
+}
+
+int use_device(const psim_handle *h)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    return PSIM_OK;
+}
+
+#define CHECK_HANDLE(h)                                              \
+    do {                                                             \
+        if (!(h)) return fail(PSIM_ERR_INVALID, "null handle");      \
+        int rc_ = use_device(h);                                     \
+        if (rc_ != PSIM_OK) return rc_;                              \
+    } while (0)
+
+int create_impl(psim_handle **out, uint32_t count, uint64_t global_first, uint64_t global_count,
+                int generation_mode, int device_id)
+{
+    if (!out) return fail(PSIM_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (generation_mode < PSIM_GEN_HOLLOW || generation_mode > PSIM_GEN_UNIFORM)
+        return fail(PSIM_ERR_INVALID, "unknown generation mode %d", generation_mode);
+    if (global_count && (global_first > global_count || count > global_count - global_first))
+        return fail(PSIM_ERR_INVALID, "shard [%llu, +%u) exceeds global count %llu",
+                    (unsigned long long)global_first, count, (unsigned long long)global_count);
+    if (global_count > 0xFFFFFFFFull && generation_mode != PSIM_GEN_UNIFORM)
+        return fail(PSIM_ERR_INVALID, "the reference generators index particles with u32");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PSIM_ERR_NO_DEVICE, "no HIP device visible (this backend has no CPU path)");
+    if (device_id < 0 || device_id >= ndev)
+        return fail(PSIM_ERR_INVALID, "device %d out of range (%d visible)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !env_int("PSIM_ALLOW_ANY_ARCH", 0))
+        return fail(PSIM_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                    device_id, prop.gcnArchName);
+
+    psim_handle *h = new (std::nothrow) psim_handle();
+    if (!h) return fail(PSIM_ERR_NOMEM, "host allocation failed");
+    h->device = device_id;
+    h->num_cus = prop.multiProcessorCount;
+    h->count = count;
+    h->global_first = global_first;
+    h->global_count = global_count;
+    h->generation_mode = generation_mode;
+    h->tuning.max_blocks = (uint32_t)env_int("PSIM_MAX_BLOCKS", 0);
+    h->tuning.nontemporal = env_int("PSIM_NT", 1);
+    h->tuning.unroll = env_int("PSIM_UNROLL", 1);
+    int rc = PSIM_OK;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        rc = fail(PSIM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    } else {
+        h->stream = h->own_stream;
+        rc = allocate(h, round_capacity(count));
+        if (rc == PSIM_OK) rc = generate(h, generation_mode);
+        if (rc == PSIM_OK) {
+            e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess)
+                rc = fail(PSIM_ERR_HIP, "initial generation failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (rc != PSIM_OK) {
+        psim_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return PSIM_OK;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+// ---- lifecycle --------------------------------------------------------------
+
+PSIM_API int psim_create(psim_handle **out, uint32_t count, int generation_mode, int device_id)
+{
+    return create_impl(out, count, 0, 0, generation_mode, device_id);
+}
+
+PSIM_API int psim_create_shard(psim_handle **out, uint32_t count, uint64_t global_first,
+                               uint64_t global_count, int generation_mode, int device_id)
+{
+    if (global_count == 0) return fail(PSIM_ERR_INVALID, "global_count must be > 0 for a shard");
+    return create_impl(out, count, global_first, global_count, generation_mode, device_id);
+}
+
+PSIM_API void psim_destroy(psim_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+    if (h->aos_stage) (void)hipFree(h->aos_stage);
+    if (h->slab) (void)hipFree(h->slab);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+// ---- the hot path -----------------------------------------------------------
+
+PSIM_API int psim_update(psim_handle *h, const psim_sim_params *params)
+{
+    CHECK_HANDLE(h);
+    if (!params) return fail(PSIM_ERR_INVALID, "null params");
+    const int force = params->is_mouse_dragging > 0 ? 1 : 0;
+    HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, nullptr, 0, h->tuning,
+                                h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_update_multi(psim_handle *h, const psim_sim_params *params,
+                               const psim_attractor *attractors_device, uint32_t n_attractors)
+{
+    CHECK_HANDLE(h);
+    if (!params) return fail(PSIM_ERR_INVALID, "null params");
+    if (n_attractors > PSIM_MAX_ATTRACTORS)
+        return fail(PSIM_ERR_INVALID, "%u attractors exceed the maximum of %u", n_attractors,
+                    PSIM_MAX_ATTRACTORS);
+    if (n_attractors && !attractors_device) return fail(PSIM_ERR_INVALID, "null attractor list");
+    if (n_attractors && (reinterpret_cast<uintptr_t>(attractors_device) & 3u))
+        return fail(PSIM_ERR_INVALID, "attractor list must be 4-byte aligned");
+    const int force = n_attractors ? 2 : 0;
+    HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, attractors_device, nullptr,
+                                n_attractors, h->tuning, h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *params,
+                                    const psim_attractor *attractors_host, uint32_t n_attractors)
+{
+    CHECK_HANDLE(h);
+    if (!params) return fail(PSIM_ERR_INVALID, "null params");
+    if (n_attractors > PSIM_KERNARG_ATTRACTORS)
+        return fail(PSIM_ERR_INVALID, "%u attractors exceed the host-list maximum of %u",
+                    n_attractors, PSIM_KERNARG_ATTRACTORS);
+    if (n_attractors && !attractors_host) return fail(PSIM_ERR_INVALID, "null attractor list");
+    const int force = n_attractors ? 3 : 0;
+    HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, attractors_host,
+                                n_attractors, h->tuning, h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *vy, float *vz,
+                             float *color, uint32_t count, const psim_sim_params *params,
+                             void *hip_stream)
+{
+    if (!params) return fail(PSIM_ERR_INVALID, "null params");
+    if (count == 0) return PSIM_OK;
+    if (!px || !py || !pz || !vx || !vy || !vz) return fail(PSIM_ERR_INVALID, "null state array");
+    const bool colours = params->color_mode == 1 || params->color_mode == 2;
+    if (colours && !color)
+        return fail(PSIM_ERR_INVALID, "color_mode %u needs a colour array", params->color_mode);
+    psim::SoaPtrs s = {px, py, pz, vx, vy, vz, color, nullptr, nullptr};
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const bool vec = aligned16(px) && aligned16(py) && aligned16(pz) && aligned16(vx) &&
+                     aligned16(vy) && aligned16(vz) && (!colours || aligned16(color));
+    if (vec) {
+        psim::LaunchTuning t = {(uint32_t)env_int("PSIM_MAX_BLOCKS", 0), env_int("PSIM_NT", 1),
+                                env_int("PSIM_UNROLL", 1)};
+        HIP_TRY(psim::launch_update(s, count, *params, params->is_mouse_dragging > 0 ? 1 : 0,
+                                    nullptr, nullptr, 0, t, stream));
+    } else {
+        if (reinterpret_cast<uintptr_t>(px) & 3u)
+            return fail(PSIM_ERR_INVALID, "state arrays must be 4-byte aligned");
+        HIP_TRY(psim::launch_update_scalar(s, count, *params, 0, stream));
+    }
+    return PSIM_OK;
+}
+
+PSIM_API int psim_store_attractor(psim_handle *h, psim_attractor *dst_device,
+                                  const psim_attractor *value_host)
+{
+    CHECK_HANDLE(h);
+    if (!dst_device || !value_host) return fail(PSIM_ERR_INVALID, "null attractor pointer");
+    HIP_TRY(psim::launch_store_attractor(dst_device, *value_host, h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_sync(psim_handle *h)
+{
+    CHECK_HANDLE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+// ---- state management -------------------------------------------------------
+
+PSIM_API int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode)
+{
+    CHECK_HANDLE(h);
+    if (generation_mode < PSIM_GEN_HOLLOW || generation_mode > PSIM_GEN_UNIFORM)
+        return fail(PSIM_ERR_INVALID, "unknown generation mode %d", generation_mode);
+    h->generation_mode = generation_mode;            // compute.rs:153
+    if (new_count == h->count) return PSIM_OK;       // compute.rs:155-157
+    if (h->global_count)
+        return fail(PSIM_ERR_INVALID, "a shard cannot be resized; recreate the shards");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (new_count > h->capacity) {                   // compute.rs:162-186: new buffer
+        void *old = h->slab;
+        int rc = allocate(h, round_capacity(new_count));
+        if (rc != PSIM_OK) return rc;                // old storage stays valid
+        (void)hipFree(old);
+    }
+    h->count = new_count;
+    int rc = generate(h, generation_mode);           // compute.rs:160: all particles
+    if (rc != PSIM_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_reset(psim_handle *h, int generation_mode)
+{
+    CHECK_HANDLE(h);
+    if (generation_mode < PSIM_GEN_HOLLOW || generation_mode > PSIM_GEN_UNIFORM)
+        return fail(PSIM_ERR_INVALID, "unknown generation mode %d", generation_mode);
+    h->generation_mode = generation_mode;            // compute.rs:212
+    int rc = generate(h, generation_mode);           // compute.rs:213-215
+    if (rc != PSIM_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API uint32_t psim_particle_count(const psim_handle *h) { return h ? h->count : 0; }
+
+PSIM_API int psim_method(const psim_handle *h)
+{
+    (void)h;
+    return PSIM_METHOD_HIP;
+}
+
+PSIM_API int psim_is_paused(const psim_handle *h) { return h && h->paused ? 1 : 0; }
+
+PSIM_API void psim_set_paused(psim_handle *h, int paused)
+{
+    if (h) h->paused = paused != 0;
+}
+
+// ---- particle data in and out -------------------------------------------------
+
+PSIM_API int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n)
+{
+    CHECK_HANDLE(h);
+    int rc = check_range(h, first, n);
+    if (rc != PSIM_OK) return rc;
+    if (n == 0) return PSIM_OK;
+    if (!dst_host) return fail(PSIM_ERR_INVALID, "null destination");
+    rc = ensure_stage(h);
+    if (rc != PSIM_OK) return rc;
+    for (uint64_t done = 0; done < n; done += kStageParticles) {
+        const uint32_t m = (uint32_t)((n - done) < kStageParticles ? (n - done) : kStageParticles);
+        HIP_TRY(psim::launch_export_aos(h->soa, (uint32_t)(first + done), m, h->aos_stage,
+                                        h->stream));
+        HIP_TRY(hipMemcpyAsync(dst_host + done, h->aos_stage, (size_t)m * sizeof(psim_particle),
+                               hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return PSIM_OK;
+}
+
+PSIM_API int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint64_t first,
+                             uint64_t n)
+{
+    CHECK_HANDLE(h);
+    int rc = check_range(h, first, n);
+    if (rc != PSIM_OK) return rc;
+    if (n == 0) return PSIM_OK;
+    if (!src_host) return fail(PSIM_ERR_INVALID, "null source");
+    return upload_aos_chunked(h, src_host, first, n);
+}
+
+PSIM_API int psim_download_soa(psim_handle *h, float *dst_host, uint64_t first, uint64_t n)
+{
+    CHECK_HANDLE(h);
+    int rc = check_range(h, first, n);
+    if (rc != PSIM_OK) return rc;
+    if (n == 0) return PSIM_OK;
+    if (!dst_host) return fail(PSIM_ERR_INVALID, "null destination");
+    const float *arr[6] = {h->soa.px, h->soa.py, h->soa.pz, h->soa.vx, h->soa.vy, h->soa.vz};
+    for (int k = 0; k < 6; ++k)
+        HIP_TRY(hipMemcpyAsync(dst_host + (uint64_t)k * n, arr[k] + first, n * sizeof(float),
+                               hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_upload_soa(psim_handle *h, const float *src_host, uint64_t first, uint64_t n)
+{
+    CHECK_HANDLE(h);
+    int rc = check_range(h, first, n);
+    if (rc != PSIM_OK) return rc;
+    if (n == 0) return PSIM_OK;
+    if (!src_host) return fail(PSIM_ERR_INVALID, "null source");
+    float *arr[6] = {h->soa.px, h->soa.py, h->soa.pz, h->soa.vx, h->soa.vy, h->soa.vz};
+    for (int k = 0; k < 6; ++k)
+        HIP_TRY(hipMemcpyAsync(arr[k] + first, src_host + (uint64_t)k * n, n * sizeof(float),
+                               hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_export_aos_device(psim_handle *h, psim_particle *dst_device, uint64_t first,
+                                    uint64_t n)
+{
+    CHECK_HANDLE(h);
+    int rc = check_range(h, first, n);
+    if (rc != PSIM_OK) return rc;
+    if (n == 0) return PSIM_OK;
+    if (!dst_device || !aligned16(dst_device))
+        return fail(PSIM_ERR_INVALID, "AoS device buffer must be non-null and 16-byte aligned");
+    HIP_TRY(psim::launch_export_aos(h->soa, (uint32_t)first, (uint32_t)n, dst_device, h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_import_aos_device(psim_handle *h, const psim_particle *src_device,
+                                    uint64_t first, uint64_t n)
+{
+    CHECK_HANDLE(h);
+    int rc = check_range(h, first, n);
+    if (rc != PSIM_OK) return rc;
+    if (n == 0) return PSIM_OK;
+    if (!src_device || !aligned16(src_device))
+        return fail(PSIM_ERR_INVALID, "AoS device buffer must be non-null and 16-byte aligned");
+    HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)first, (uint32_t)n, src_device, h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_device_soa(psim_handle *h, psim_soa_view *view)
+{
+    if (!h || !view) return fail(PSIM_ERR_INVALID, "null argument");
+    view->px = h->soa.px; view->py = h->soa.py; view->pz = h->soa.pz;
+    view->vx = h->soa.vx; view->vy = h->soa.vy; view->vz = h->soa.vz;
+    view->color = h->soa.color;
+    view->initial_color = h->soa.initial_color;
+    view->padding = h->soa.padding;
+    view->count = h->count;
+    view->capacity = h->capacity;
+    return PSIM_OK;
+}
+
+PSIM_API int psim_checksum(psim_handle *h, uint64_t out[6])
+{
+    CHECK_HANDLE(h);
+    if (!out) return fail(PSIM_ERR_INVALID, "null output");
+    HIP_TRY(psim::launch_checksum(h->soa, h->count, h->checksum_dev, (uint32_t)h->num_cus * 16u,
+                                  h->stream));
+    HIP_TRY(hipMemcpyAsync(out, h->checksum_dev, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+// ---- streams ------------------------------------------------------------------
+
+PSIM_API int psim_set_stream(psim_handle *h, void *hip_stream)
+{
+    CHECK_HANDLE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));        // drain work queued on the old stream
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return PSIM_OK;
+}
+
+PSIM_API void *psim_get_stream(const psim_handle *h) { return h ? h->stream : nullptr; }
+
+PSIM_API int psim_device(const psim_handle *h) { return h ? h->device : -1; }
+
+// ---- timing -------------------------------------------------------------------
+
+PSIM_API int psim_timer_start(psim_handle *h)
+{
+    CHECK_HANDLE(h);
+    if (!h->ev_start) {
+        HIP_TRY(hipEventCreate(&h->ev_start));
+        HIP_TRY(hipEventCreate(&h->ev_stop));
+    }
+    HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_timer_stop(psim_handle *h, float *elapsed_ms)
+{
+    CHECK_HANDLE(h);
+    if (!elapsed_ms) return fail(PSIM_ERR_INVALID, "null output");
+    if (!h->ev_start) return fail(PSIM_ERR_INVALID, "psim_timer_stop without psim_timer_start");
+    HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev_stop));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
+    return PSIM_OK;
+}
+
+// ---- errors -------------------------------------------------------------------
+
+PSIM_API const char *psim_last_error(void) { return g_error; }
+
+PSIM_API const char *psim_version(void) { return "psim-hip 0.1 (gfx950)"; }

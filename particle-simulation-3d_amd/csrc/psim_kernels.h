@@ -1,0 +1,58 @@
+// psim_kernels.h -- host-callable launchers of the gfx950 kernels (internal).
+#ifndef PSIM_KERNELS_H
+#define PSIM_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/psim.h"
+
+#define PSIM_BLOCK 256               /* threads per workgroup = 4 wave64 */
+#define PSIM_KERNARG_ATTRACTORS 8u   /* attractor list size that fits the kernel arguments */
+
+namespace psim {
+
+// Device pointers of one particle set (structure of arrays).
+struct SoaPtrs {
+    float *px, *py, *pz, *vx, *vy, *vz;
+    float *color;          // 4 floats per particle (may be null for colour mode 0)
+    float *initial_color;  // 4 floats per particle (may be null for the update)
+    float *padding;        // 2 floats per particle (may be null for the update)
+};
+
+// Launch shape of the update kernel.
+struct LaunchTuning {
+    uint32_t max_blocks;   // 0 = one pass (grid covers every group), else grid-stride cap
+    int nontemporal;       // non-temporal loads/stores
+    int unroll;            // float4 groups per lane per trip: 1 or 2
+};
+
+uint32_t update_grid(uint32_t n, const LaunchTuning &t);
+
+// force: 0 none, 1 the SimParams attractor, 2 list in device memory (staged in
+// LDS), 3 list copied from host memory into the kernel arguments.
+hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &p, int force,
+                         const psim_attractor *attr_dev, const psim_attractor *attr_host,
+                         uint32_t na, const LaunchTuning &t, hipStream_t stream);
+
+hipError_t launch_update_scalar(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
+                                uint32_t max_blocks, hipStream_t stream);
+
+hipError_t launch_store_attractor(psim_attractor *dst, const psim_attractor &value,
+                                  hipStream_t stream);
+
+hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_first, uint64_t seed,
+                              uint32_t max_blocks, hipStream_t stream);
+
+hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
+                             hipStream_t stream);
+hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
+                             const psim_particle *aos, hipStream_t stream);
+
+hipError_t launch_checksum(const SoaPtrs &s, uint32_t n, uint64_t *out_dev, uint32_t max_blocks,
+                           hipStream_t stream);
+
+}  // namespace psim
+
+#endif

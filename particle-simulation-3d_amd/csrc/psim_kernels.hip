@@ -1,0 +1,514 @@
+// psim_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the particle-update path.
+//
+// The update is a pure HBM stream: 24 B read + 24 B written per particle
+// (px,py,pz,vx,vy,vz as six fp32 arrays), < 1 flop/B, so there is no MFMA here.
+// Each lane moves 16 B per array per access (global_load/store_dwordx4, 1 KiB
+// per wave instruction); the step constants arrive as kernel arguments (SGPRs);
+// the attractor list of the multi-attractor form is staged once per workgroup
+// into LDS and read back as same-address broadcasts.
+//
+// Arithmetic follows the reference CPU path (src/simulation/cpu.rs:65-113) one
+// rounding per source-level operation: this file is compiled with
+// -ffp-contract=off (rustc never forms FMAs) and with hipcc's default correctly
+// rounded fp32 divide and sqrt, denormals kept.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "psim_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace psim {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- memory access helpers -------------------------------------------------
+
+template <bool NT, typename T>
+__device__ __forceinline__ T ld(const T *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <bool NT, typename T>
+__device__ __forceinline__ void st(T *p, T v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// ---- the per-particle step (src/simulation/cpu.rs:66-112) -------------------
+
+struct Vec3 {
+    float x, y, z;
+};
+
+// glam Vec3::length: sqrt((x*x + y*y) + z*z).
+__device__ __forceinline__ float length3(float x, float y, float z)
+{
+    return sqrtf((x * x + y * y) + z * z);
+}
+
+// Force law of one attractor, cpu.rs:76-83.  `two_r` is radius * 2.0.
+__device__ __forceinline__ void attract(float &vx, float &vy, float &vz, float px, float py,
+                                        float pz, float ax, float ay, float az, float aforce,
+                                        float two_r, float dt)
+{
+    const float dx = ax - px, dy = ay - py, dz = az - pz;    // cpu.rs:76
+    const float dist = length3(dx, dy, dz);                  // cpu.rs:77
+    if (dist < two_r) {                                      // cpu.rs:79
+        const float t = 1.0f - dist / two_r;
+        const float ff = (t * t) * 2.0f;                     // cpu.rs:80 powi(2) * 2.0
+        const float inv = 1.0f / dist;                       // normalize = dir * (1/len)
+        const float fx = ((dx * inv) * aforce) * ff;         // cpu.rs:81
+        const float fy = ((dy * inv) * aforce) * ff;
+        const float fz = ((dz * inv) * aforce) * ff;
+        vx = vx + fx * dt;                                   // cpu.rs:82
+        vy = vy + fy * dt;
+        vz = vz + fz * dt;
+    }
+}
+
+// FORCE: 0 = no attractor, 1 = the single attractor of SimParams,
+//        2 = attractor list in LDS, 3 = attractor list in kernel arguments.
+template <int FORCE>
+__device__ __forceinline__ void step(float &px, float &py, float &pz, float &vx, float &vy,
+                                     float &vz, const psim_sim_params &p,
+                                     const psim_attractor *alist, uint32_t na)
+{
+    const float dt = p.delta_time;
+    vy = vy - p.gravity * dt;                                // cpu.rs:72
+    if constexpr (FORCE == 1) {
+        attract(vx, vy, vz, px, py, pz, p.mouse_position[0], p.mouse_position[1],
+                p.mouse_position[2], p.mouse_force, p.mouse_radius * 2.0f, dt);
+    } else if constexpr (FORCE >= 2) {
+        for (uint32_t a = 0; a < na; ++a) {
+            if (alist[a].active > 0)
+                attract(vx, vy, vz, px, py, pz, alist[a].position[0], alist[a].position[1],
+                        alist[a].position[2], alist[a].force, alist[a].radius * 2.0f, dt);
+        }
+    }
+    px = px + vx * dt;                                       // cpu.rs:87
+    py = py + vy * dt;
+    pz = pz + vz * dt;
+    vx = vx * p.damping;                                     // cpu.rs:90
+    vy = vy * p.damping;
+    vz = vz * p.damping;
+}
+
+// Colour of one particle for modes 1 and 2 (cpu.rs:93-105), from the damped
+// velocity / the new position.
+template <int CM>
+__device__ __forceinline__ f32x4 colour(float px, float py, float pz, float vx, float vy,
+                                        float vz, const psim_sim_params &p)
+{
+    f32x4 c;
+    if constexpr (CM == 1) {
+        const float speed = length3(vx, vy, vz);
+        const float ns = fminf(speed / 5.0f, 1.0f);          // f32::min ignores NaN
+        c = f32x4{ns, 0.5f - ns * 0.5f, 1.0f - ns, 1.0f};
+    } else {
+        const float d = length3(px, py, pz);
+        float nd = d / fmaxf(p.max_dist_for_color, 0.01f);
+        nd = nd < 0.0f ? 0.0f : nd;                          // f32::clamp keeps NaN
+        nd = nd > 1.0f ? 1.0f : nd;
+        c = f32x4{nd, 0.0f, 1.0f - nd, 1.0f};
+    }
+    return c;
+}
+
+struct KernargAttractors {
+    psim_attractor a[PSIM_KERNARG_ATTRACTORS];
+};
+
+// ---- the update kernel -----------------------------------------------------
+//
+// CM    colour mode 0 (colour untouched, 48 B/particle), 1 or 2 (+16 B store).
+// FORCE see step().
+// NT    non-temporal loads and stores (the state is streamed once per step).
+// U     float4 groups per lane per loop trip (U*4 particles, 6*U loads in flight).
+//
+// Grid-stride over groups of 4 consecutive particles; a launch whose grid covers
+// every group runs the loop once.  The last n % 4 particles are stepped one at a
+// time by workgroup 0.
+template <int CM, int FORCE, bool NT, int U>
+__global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t n,
+                                                           psim_sim_params p,
+                                                           const psim_attractor *attr_dev,
+                                                           uint32_t na, KernargAttractors ka)
+{
+    const psim_attractor *alist = nullptr;
+    if constexpr (FORCE == 2) {
+        // Stage the attractor list (<= 2 KiB) into LDS once per workgroup.
+        __shared__ psim_attractor lds_attr[PSIM_MAX_ATTRACTORS];
+        const uint32_t words = na * (sizeof(psim_attractor) / 4u);
+        for (uint32_t w = threadIdx.x; w < words; w += PSIM_BLOCK)
+            reinterpret_cast<uint32_t *>(lds_attr)[w] =
+                reinterpret_cast<const uint32_t *>(attr_dev)[w];
+        __syncthreads();
+        alist = lds_attr;
+    } else if constexpr (FORCE == 3) {
+        alist = ka.a;
+    }
+
+    f32x4 *px4 = reinterpret_cast<f32x4 *>(s.px), *py4 = reinterpret_cast<f32x4 *>(s.py),
+          *pz4 = reinterpret_cast<f32x4 *>(s.pz), *vx4 = reinterpret_cast<f32x4 *>(s.vx),
+          *vy4 = reinterpret_cast<f32x4 *>(s.vy), *vz4 = reinterpret_cast<f32x4 *>(s.vz);
+    f32x4 *col4 = reinterpret_cast<f32x4 *>(s.color);
+
+    const uint32_t ngroups = n >> 2;
+    const uint32_t stride = gridDim.x * PSIM_BLOCK;          // groups per grid pass
+    // A trip handles U groups per lane, `stride` apart, so every wave instruction
+    // still covers 1 KiB of consecutive addresses.
+    for (uint32_t g0 = blockIdx.x * PSIM_BLOCK + threadIdx.x; g0 < ngroups; g0 += stride * U) {
+        f32x4 x[U], y[U], z[U], u[U], v[U], w[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t g = g0 + k * stride;
+            if (g < ngroups) {
+                x[k] = ld<NT>(px4 + g); y[k] = ld<NT>(py4 + g); z[k] = ld<NT>(pz4 + g);
+                u[k] = ld<NT>(vx4 + g); v[k] = ld<NT>(vy4 + g); w[k] = ld<NT>(vz4 + g);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t g = g0 + k * stride;
+            if (g < ngroups) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = x[k][j], b = y[k][j], c = z[k][j];
+                    float d = u[k][j], e = v[k][j], f = w[k][j];
+                    step<FORCE>(a, b, c, d, e, f, p, alist, na);
+                    x[k][j] = a; y[k][j] = b; z[k][j] = c;
+                    u[k][j] = d; v[k][j] = e; w[k][j] = f;
+                }
+                st<NT>(px4 + g, x[k]); st<NT>(py4 + g, y[k]); st<NT>(pz4 + g, z[k]);
+                st<NT>(vx4 + g, u[k]); st<NT>(vy4 + g, v[k]); st<NT>(vz4 + g, w[k]);
+                if constexpr (CM != 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        st<NT>(col4 + 4ull * g + j,
+                               colour<CM>(x[k][j], y[k][j], z[k][j], u[k][j], v[k][j], w[k][j], p));
+                }
+            }
+        }
+    }
+
+    // Tail: particles 4*ngroups .. n-1.
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
+        const uint32_t i = (ngroups << 2) + threadIdx.x;
+        float x = s.px[i], y = s.py[i], z = s.pz[i], u = s.vx[i], v = s.vy[i], w = s.vz[i];
+        step<FORCE>(x, y, z, u, v, w, p, alist, na);
+        s.px[i] = x; s.py[i] = y; s.pz[i] = z;
+        s.vx[i] = u; s.vy[i] = v; s.vz[i] = w;
+        if constexpr (CM != 0) col4[i] = colour<CM>(x, y, z, u, v, w, p);
+    }
+}
+
+// One particle per lane, 4-byte accesses: for caller-owned arrays that are not
+// 16-byte aligned (psim_update_soa only).
+template <int CM, int FORCE>
+__global__ void __launch_bounds__(PSIM_BLOCK) update_kernel_scalar(SoaPtrs s, uint32_t n,
+                                                                  psim_sim_params p)
+{
+    const uint32_t stride = gridDim.x * PSIM_BLOCK;
+    for (uint32_t i = blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
+        float x = s.px[i], y = s.py[i], z = s.pz[i], u = s.vx[i], v = s.vy[i], w = s.vz[i];
+        step<FORCE>(x, y, z, u, v, w, p, nullptr, 0);
+        s.px[i] = x; s.py[i] = y; s.pz[i] = z;
+        s.vx[i] = u; s.vy[i] = v; s.vz[i] = w;
+        if constexpr (CM != 0) {
+            const f32x4 c = colour<CM>(x, y, z, u, v, w, p);
+            float *dst = s.color + 4ull * i;                 // may be only 4-byte aligned
+            dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3];
+        }
+    }
+}
+
+// ---- launch dispatch -------------------------------------------------------
+
+template <int CM, int FORCE, bool NT, int U>
+static hipError_t launch_one(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
+                             const psim_attractor *attr_dev, uint32_t na,
+                             const KernargAttractors &ka, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((update_kernel<CM, FORCE, NT, U>), dim3(grid), dim3(PSIM_BLOCK), 0, stream,
+                       s, n, p, attr_dev, na, ka);
+    return hipGetLastError();
+}
+
+template <int CM, int FORCE>
+static hipError_t launch_nt_u(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
+                              const psim_attractor *attr_dev, uint32_t na,
+                              const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
+                              hipStream_t stream)
+{
+    if (t.nontemporal) {
+        if (t.unroll >= 2) return launch_one<CM, FORCE, true, 2>(s, n, p, attr_dev, na, ka, grid, stream);
+        return launch_one<CM, FORCE, true, 1>(s, n, p, attr_dev, na, ka, grid, stream);
+    }
+    if (t.unroll >= 2) return launch_one<CM, FORCE, false, 2>(s, n, p, attr_dev, na, ka, grid, stream);
+    return launch_one<CM, FORCE, false, 1>(s, n, p, attr_dev, na, ka, grid, stream);
+}
+
+template <int FORCE>
+static hipError_t launch_cm(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
+                            const psim_attractor *attr_dev, uint32_t na,
+                            const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
+                            hipStream_t stream)
+{
+    switch (p.color_mode) {
+    case 1: return launch_nt_u<1, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    case 2: return launch_nt_u<2, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    default: return launch_nt_u<0, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    }
+}
+
+uint32_t update_grid(uint32_t n, const LaunchTuning &t)
+{
+    const uint32_t ngroups = n >> 2;
+    const uint32_t per_block = PSIM_BLOCK * (t.unroll >= 2 ? 2u : 1u);
+    uint32_t need = (ngroups + per_block - 1u) / per_block;
+    if (need == 0) need = 1;                                  // the tail still needs block 0
+    if (t.max_blocks > 0 && need > t.max_blocks) need = t.max_blocks;
+    return need;
+}
+
+hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &p, int force,
+                         const psim_attractor *attr_dev, const psim_attractor *attr_host,
+                         uint32_t na, const LaunchTuning &t, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    KernargAttractors ka;
+    memset(&ka, 0, sizeof(ka));
+    if (force == 3) memcpy(ka.a, attr_host, na * sizeof(psim_attractor));
+    const uint32_t grid = update_grid(n, t);
+    switch (force) {
+    case 0: return launch_cm<0>(s, n, p, nullptr, 0, ka, t, grid, stream);
+    case 1: return launch_cm<1>(s, n, p, nullptr, 0, ka, t, grid, stream);
+    case 2: return launch_cm<2>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    default: return launch_cm<3>(s, n, p, nullptr, na, ka, t, grid, stream);
+    }
+}
+
+hipError_t launch_update_scalar(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
+                                uint32_t max_blocks, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+    const bool drag = p.is_mouse_dragging > 0;
+#define PSIM_SCALAR(CM, F)                                                                      \
+    hipLaunchKernelGGL((update_kernel_scalar<CM, F>), dim3(grid), dim3(PSIM_BLOCK), 0, stream, \
+                       s, n, p)
+    switch (p.color_mode) {
+    case 1: if (drag) PSIM_SCALAR(1, 1); else PSIM_SCALAR(1, 0); break;
+    case 2: if (drag) PSIM_SCALAR(2, 1); else PSIM_SCALAR(2, 0); break;
+    default: if (drag) PSIM_SCALAR(0, 1); else PSIM_SCALAR(0, 0); break;
+    }
+#undef PSIM_SCALAR
+    return hipGetLastError();
+}
+
+// ---- attractor staging -----------------------------------------------------
+
+__global__ void store_attractor_kernel(psim_attractor *dst, psim_attractor value)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = value;
+}
+
+hipError_t launch_store_attractor(psim_attractor *dst, const psim_attractor &value,
+                                  hipStream_t stream)
+{
+    hipLaunchKernelGGL(store_attractor_kernel, dim3(1), dim3(64), 0, stream, dst, value);
+    return hipGetLastError();
+}
+
+// ---- synthetic uniform state -----------------------------------------------
+
+// Counter-based SplitMix64: the value depends only on (seed, counter).
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t counter)
+{
+    uint64_t z = seed + (counter + 1u) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ float unit_at(uint64_t seed, uint64_t counter)
+{
+    return (float)(uint32_t)(splitmix64_at(seed, counter) >> 40) * 0x1.0p-24f;
+}
+
+// Particle with global index g: position U[-50,50)^3, velocity U[-1,1)^3, colour
+// (pos/50 + 1) * 0.5 with alpha 1 (the reference's colour rule,
+// src/simulation/mod.rs:162-163), paddings 0.  One particle per lane.
+__global__ void __launch_bounds__(PSIM_BLOCK) gen_uniform_kernel(SoaPtrs s, uint32_t n,
+                                                                uint64_t global_first,
+                                                                uint64_t seed)
+{
+    const uint32_t stride = gridDim.x * PSIM_BLOCK;
+    for (uint32_t i = blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint64_t c0 = 6ull * (global_first + i);
+        float pos[3], vel[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pos[c] = unit_at(seed, c0 + c) * 100.0f - 50.0f;
+            vel[c] = unit_at(seed, c0 + 3 + c) * 2.0f - 1.0f;
+        }
+        s.px[i] = pos[0]; s.py[i] = pos[1]; s.pz[i] = pos[2];
+        s.vx[i] = vel[0]; s.vy[i] = vel[1]; s.vz[i] = vel[2];
+        const f32x4 col = {(pos[0] / 50.0f + 1.0f) * 0.5f, (pos[1] / 50.0f + 1.0f) * 0.5f,
+                           (pos[2] / 50.0f + 1.0f) * 0.5f, 1.0f};
+        reinterpret_cast<f32x4 *>(s.color)[i] = col;
+        reinterpret_cast<f32x4 *>(s.initial_color)[i] = col;
+        reinterpret_cast<f32x2 *>(s.padding)[i] = f32x2{0.0f, 0.0f};
+    }
+}
+
+hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_first, uint64_t seed,
+                              uint32_t max_blocks, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+    hipLaunchKernelGGL(gen_uniform_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, n,
+                       global_first, seed);
+    return hipGetLastError();
+}
+
+// ---- AoS <-> SoA transposes ------------------------------------------------
+//
+// The 64-byte record (src/simulation/mod.rs:86-98) is four 16-byte quads:
+//   q0 = position.xyz, padding1   q1 = velocity.xyz, padding2
+//   q2 = color                    q3 = initial_color
+// A workgroup moves PSIM_BLOCK particles = 16 KiB of AoS.  The AoS side is
+// accessed as a linear run of quads (lane t touches quad k*PSIM_BLOCK + t, so a
+// wave instruction covers 1 KiB of consecutive bytes); the transposition happens
+// in LDS.  LDS holds quads at [field][particle] so both phases are conflict-free
+// 16-byte accesses.
+
+__global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint32_t first,
+                                                               uint32_t n, f32x4 *aos)
+{
+    __shared__ f32x4 tile[4][PSIM_BLOCK];
+    const uint32_t base = blockIdx.x * PSIM_BLOCK;            // first particle of the tile
+    const uint32_t t = threadIdx.x;
+    const uint32_t i = base + t;
+    if (i < n) {
+        const uint32_t src = first + i;
+        const f32x2 pad = reinterpret_cast<const f32x2 *>(s.padding)[src];
+        tile[0][t] = f32x4{s.px[src], s.py[src], s.pz[src], pad[0]};
+        tile[1][t] = f32x4{s.vx[src], s.vy[src], s.vz[src], pad[1]};
+        tile[2][t] = reinterpret_cast<const f32x4 *>(s.color)[src];
+        tile[3][t] = reinterpret_cast<const f32x4 *>(s.initial_color)[src];
+    }
+    __syncthreads();
+    const uint32_t live = (n - base) < PSIM_BLOCK ? (n - base) : PSIM_BLOCK;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t q = k * PSIM_BLOCK + t;                // quad index within the tile
+        const uint32_t particle = q >> 2, field = q & 3u;
+        if (particle < live) aos[4ull * base + q] = tile[field][particle];
+    }
+}
+
+__global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint32_t first,
+                                                               uint32_t n, const f32x4 *aos)
+{
+    __shared__ f32x4 tile[4][PSIM_BLOCK];
+    const uint32_t base = blockIdx.x * PSIM_BLOCK;
+    const uint32_t t = threadIdx.x;
+    const uint32_t live = (n - base) < PSIM_BLOCK ? (n - base) : PSIM_BLOCK;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t q = k * PSIM_BLOCK + t;
+        const uint32_t particle = q >> 2, field = q & 3u;
+        if (particle < live) tile[field][particle] = aos[4ull * base + q];
+    }
+    __syncthreads();
+    const uint32_t i = base + t;
+    if (i < n) {
+        const uint32_t dst = first + i;
+        const f32x4 q0 = tile[0][t], q1 = tile[1][t];
+        s.px[dst] = q0[0]; s.py[dst] = q0[1]; s.pz[dst] = q0[2];
+        s.vx[dst] = q1[0]; s.vy[dst] = q1[1]; s.vz[dst] = q1[2];
+        reinterpret_cast<f32x2 *>(s.padding)[dst] = f32x2{q0[3], q1[3]};
+        reinterpret_cast<f32x4 *>(s.color)[dst] = tile[2][t];
+        reinterpret_cast<f32x4 *>(s.initial_color)[dst] = tile[3][t];
+    }
+}
+
+hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
+                             hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    hipLaunchKernelGGL(export_aos_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, first, n,
+                       reinterpret_cast<f32x4 *>(aos));
+    return hipGetLastError();
+}
+
+hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
+                             const psim_particle *aos, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    hipLaunchKernelGGL(import_aos_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, first, n,
+                       reinterpret_cast<const f32x4 *>(aos));
+    return hipGetLastError();
+}
+
+// ---- checksums (wavefront reductions) ---------------------------------------
+
+// Sum of a 64-bit value over the 64 lanes of a wave, result in lane 0.
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// out[k] += sum over particles of the bit pattern of component k.  Integer sums
+// commute, so the result does not depend on the schedule.
+__global__ void __launch_bounds__(PSIM_BLOCK) checksum_kernel(SoaPtrs s, uint32_t n,
+                                                             unsigned long long *out)
+{
+    const float *arr[6] = {s.px, s.py, s.pz, s.vx, s.vy, s.vz};
+    uint64_t acc[6] = {0, 0, 0, 0, 0, 0};
+    const uint32_t stride = gridDim.x * PSIM_BLOCK;
+    for (uint32_t i = blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += __float_as_uint(arr[k][i]);
+    }
+    __shared__ uint64_t partial[PSIM_BLOCK / 64][6];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint64_t w = wave_sum_u64(acc[k]);
+        if (lane == 0) partial[wave][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        uint64_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < PSIM_BLOCK / 64; ++w) tot += partial[w][threadIdx.x];
+        atomicAdd(&out[threadIdx.x], (unsigned long long)tot);
+    }
+}
+
+hipError_t launch_checksum(const SoaPtrs &s, uint32_t n, uint64_t *out_dev, uint32_t max_blocks,
+                           hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(out_dev, 0, 6 * sizeof(uint64_t), stream);
+    if (e != hipSuccess || n == 0) return e;
+    uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+    hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, n,
+                       reinterpret_cast<unsigned long long *>(out_dev));
+    return hipGetLastError();
+}
+
+}  // namespace psim

@@ -1,0 +1,210 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle
+and the committed golden vectors.
+
+Bar: fp32 within 1e-5 relative of the reference CPU arithmetic.  The kernels round
+every operation like the oracle does, so these tests demand BIT equality of every
+finite value (NaNs must sit in the same places); a failure message reports the
+relative error against the 1e-5 bar.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import psim_testlib as T
+from psim_testlib import psim
+
+pytestmark = pytest.mark.gpu
+
+Sim = psim.HipParticleSimulation
+STEPS_LONG = 100
+
+
+def golden_names():
+    g = np.load(os.path.join(T.GOLDEN_DIR, "update_cases.npz"))
+    return [str(n) for n in g["names"]]
+
+
+def load_case(golden, name):
+    particles = golden[f"{name}.in"].view(psim.PARTICLE_DTYPE)
+    params = T.params_from_bytes(golden[f"{name}.params"])
+    key = f"{name}.attractors"
+    attractors = golden[key].view(psim.ATTRACTOR_DTYPE) if key in golden.files else None
+    return particles, params, attractors
+
+
+def run_gpu(particles, params, steps, attractors=None):
+    with Sim.new(len(particles), psim.GEN_UNIFORM) as sim:
+        sim.upload_aos(particles)
+        for _ in range(steps):
+            if attractors is None:
+                sim.update(params)
+            else:
+                sim.update_multi(params, attractors)
+        return sim.download_aos()
+
+
+# ---- golden vectors ------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_case(golden_update, name):
+    particles, params, attractors = load_case(golden_update, name)
+    for steps in (1, STEPS_LONG):
+        want = golden_update[f"{name}.out{steps}"].view(psim.PARTICLE_DTYPE)
+        got = run_gpu(particles, params, steps, attractors)
+        T.assert_particles_equal(got, want, f"{name}/{steps} steps")
+
+
+# ---- BASELINE configurations against the oracle ---------------------------------------
+
+@pytest.mark.parametrize("n", [100_000, 1_000_003])
+@pytest.mark.parametrize("kw", [
+    dict(),                                                         # the benchmark parameters
+    dict(mouse_radius=50.0, mouse_force=100.0, gravity=5.0),        # UI maxima: all in range
+    dict(is_mouse_dragging=0, gravity=1.0),
+    dict(color_mode=1, mouse_radius=50.0, mouse_force=100.0),
+    dict(color_mode=2, mouse_radius=25.0),
+])
+def test_uniform_state_matches_oracle(n, kw):
+    params = T.bench_params(**kw)
+    steps = 10
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        start = sim.download_aos()
+        T.assert_particles_equal(start, T.oracle_gen_uniform_aos(0, n), "generated state")
+        for _ in range(steps):
+            sim.update(params)
+        got = sim.download_aos()
+    want = T.oracle_update_aos(start, params, steps)
+    T.assert_particles_equal(got, want, f"n={n} {kw}")
+
+
+def test_ten_million_particles_match_oracle():
+    """BASELINE config: 10 M particles, single attractor, fp32."""
+    n = 10_000_000
+    params = T.bench_params()
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        for _ in range(5):
+            sim.update(params)
+        got = sim.download_soa()
+        gpu_sum = sim.checksum()
+    want, _ = T.oracle_update_soa(T.oracle_gen_uniform_soa(0, n), params, 5)
+    T.assert_same_f32(got, want, "10M x 5 steps")
+    assert gpu_sum == T.oracle_checksum_soa(want)
+
+
+def test_hundred_million_particles_checksum_and_slices():
+    """BASELINE config: 100 M particles.  The whole state is compared through an
+    order-independent checksum (sum of bit patterns per component) computed on the
+    device and by the oracle; three slices are compared value by value."""
+    n = 100_000_000
+    params = T.bench_params()
+    steps = 3
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        for _ in range(steps):
+            sim.update(params)
+        gpu_sum = sim.checksum()
+        slices = [(0, 4096), (n // 2 - 1000, 5000), (n - 4099, 4099)]
+        got = [sim.download_soa(f, m) for f, m in slices]
+    for (f, m), g in zip(slices, got):
+        want, _ = T.oracle_update_soa(T.oracle_gen_uniform_soa(f, m), params, steps)
+        T.assert_same_f32(g, want, f"slice [{f}, +{m})")
+    want_sum = [0] * 6
+    chunk = 25_000_000                                   # 600 MB of host memory at a time
+    for f in range(0, n, chunk):
+        w, _ = T.oracle_update_soa(T.oracle_gen_uniform_soa(f, chunk), params, steps)
+        want_sum = [(a + b) % (1 << 64) for a, b in zip(want_sum, T.oracle_checksum_soa(w))]
+    assert gpu_sum == want_sum
+
+
+# ---- multi-attractor extension ----------------------------------------------------------
+
+def _attractors(rng, k):
+    a = np.zeros(k, dtype=psim.ATTRACTOR_DTYPE)
+    a["position"] = rng.uniform(-40, 40, size=(k, 3)).astype(np.float32)
+    a["force"] = rng.uniform(1, 100, size=k).astype(np.float32)
+    a["radius"] = rng.uniform(5, 50, size=k).astype(np.float32)
+    a["active"] = 1
+    return a
+
+
+@pytest.mark.parametrize("k", [1, 3, 8])
+def test_multi_attractor_host_list(k):
+    rng = np.random.default_rng(k)
+    attrs = _attractors(rng, k)
+    params = T.bench_params(gravity=0.5, color_mode=1)
+    n = 50_001
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        start = sim.download_aos()
+        for _ in range(4):
+            sim.update_multi(params, attrs)
+        got = sim.download_aos()
+    want = T.oracle_update_aos(start, params, 4, attrs)
+    T.assert_particles_equal(got, want, f"{k} attractors (host list)")
+
+
+@pytest.mark.parametrize("k", [1, 8, 64])
+def test_multi_attractor_device_list(k):
+    """The list lives in device memory (as after an all-gather) and is staged into LDS."""
+    rng = np.random.default_rng(100 + k)
+    attrs = _attractors(rng, k)
+    attrs["active"][k // 2] = 0 if k > 1 else 1
+    params = T.bench_params(gravity=0.25)
+    n = 30_011
+    with Sim.new(n, psim.GEN_UNIFORM) as sim, Sim.new(4096, psim.GEN_UNIFORM) as scratch:
+        buf = scratch.get_particle_buffer().color        # device memory for the list
+        for i in range(k):
+            sim.store_attractor(buf + 32 * i, attrs[i:i + 1])
+        start = sim.download_aos()
+        for _ in range(3):
+            sim.update_multi_device(params, buf, k)
+        got = sim.download_aos()
+    want = T.oracle_update_aos(start, params, 3, attrs)
+    T.assert_particles_equal(got, want, f"{k} attractors (device list)")
+
+
+def test_single_attractor_list_equals_update():
+    params = T.bench_params(mouse_radius=30.0, mouse_force=40.0)
+    one = np.zeros(1, dtype=psim.ATTRACTOR_DTYPE)
+    one["position"] = tuple(params.mouse_position)
+    one["force"] = params.mouse_force
+    one["radius"] = params.mouse_radius
+    one["active"] = 1
+    n = 20_000
+    with Sim.new(n, psim.GEN_UNIFORM) as a, Sim.new(n, psim.GEN_UNIFORM) as b:
+        for _ in range(5):
+            a.update(params)
+            b.update_multi(params, one)
+        assert a.download_aos().tobytes() == b.download_aos().tobytes()
+
+
+# ---- stateless entry point ----------------------------------------------------------------
+
+@pytest.mark.parametrize("offset", [0, 1, 3])
+@pytest.mark.parametrize("color_mode", [0, 2])
+def test_update_soa_on_caller_arrays(offset, color_mode):
+    """psim_update_soa over caller-owned device arrays, 16-byte aligned (offset 0) and
+    not (offsets 1 and 3 floats: the one-particle-per-lane kernel)."""
+    n = 10_007
+    params = T.bench_params(color_mode=color_mode, mouse_radius=50.0)
+    with Sim.new(n + 8, psim.GEN_UNIFORM) as sim:
+        v = sim.get_particle_buffer()
+        before = sim.download_aos()
+        ptrs = [getattr(v, k) + 4 * offset for k in ("px", "py", "pz", "vx", "vy", "vz")]
+        color = v.color + 16 * offset if color_mode else 0
+        psim.update_soa(*ptrs, color, n, params, sim.get_stream())
+        after = sim.download_aos()
+    want = T.oracle_update_aos(before[offset:offset + n], params, 1)
+    T.assert_particles_equal(after[offset:offset + n], want, "stepped range",
+                             fields=("position", "velocity", "color"))
+    untouched = np.ones(n + 8, dtype=bool)
+    untouched[offset:offset + n] = False
+    assert after[untouched].tobytes() == before[untouched].tobytes()
+
+
+# ---- checksums -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 262_147])
+def test_checksum_matches_oracle(n):
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        sim.update(T.bench_params())
+        assert sim.checksum() == T.oracle_checksum_soa(sim.download_soa())

@@ -1,0 +1,236 @@
+"""GPU tests of the state-management entry points around the update: construction,
+generators, resize / reset semantics, pause flag, AoS import / export, shards."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import psim_testlib as T
+from psim_testlib import psim
+
+pytestmark = pytest.mark.gpu
+
+Sim = psim.HipParticleSimulation
+
+
+def random_particles(n, seed=0):
+    rng = np.random.default_rng(seed)
+    p = np.zeros(n, dtype=psim.PARTICLE_DTYPE)
+    raw = rng.uniform(-100, 100, size=(n, 16)).astype(np.float32)
+    p.view(np.float32).reshape(n, 16)[:] = raw
+    return p
+
+
+# ---- trait surface -----------------------------------------------------------------------
+
+def test_new_count_method_pause():
+    with Sim.new(12_345, psim.GEN_HOLLOW) as sim:
+        assert sim.get_particle_count() == 12_345
+        assert sim.get_method() == psim.METHOD_HIP
+        assert sim.is_paused() is False                       # cpu.rs:34 / compute.rs:118
+        sim.set_paused(True)
+        assert sim.is_paused() is True
+        # like the reference, update does not consult the flag (cpu.rs:46-48 is commented
+        # out; the caller gates on is_paused, app.rs:283)
+        before = sim.download_aos()
+        sim.update(T.bench_params(gravity=1.0))
+        after = sim.download_aos()
+        assert before.tobytes() != after.tobytes()
+        sim.set_paused(False)
+        assert sim.is_paused() is False
+
+
+def test_zero_and_one_particle():
+    with Sim.new(0, psim.GEN_UNIFORM) as sim:
+        assert sim.get_particle_count() == 0
+        sim.update(T.bench_params())
+        sim.sync()
+        assert len(sim.download_aos()) == 0
+        assert sim.checksum() == [0] * 6
+    with Sim.new(1, psim.GEN_UNIFORM) as sim:
+        start = sim.download_aos()
+        sim.update(T.bench_params(mouse_radius=50.0))
+        T.assert_particles_equal(sim.download_aos(),
+                                 T.oracle_update_aos(start, T.bench_params(mouse_radius=50.0)),
+                                 "single particle")
+
+
+# ---- generators ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 2, 1000, 100_000])
+def test_hollow_generator_matches_oracle(n):
+    with Sim.new(n, psim.GEN_HOLLOW) as sim:
+        T.assert_particles_equal(sim.download_aos(), T.oracle_gen_hollow_aos(n), f"hollow {n}")
+
+
+@pytest.mark.parametrize("n", [1, 1000, 100_000])
+def test_filled_generator_matches_oracle(n):
+    with Sim.new(n, psim.GEN_FILLED) as sim:
+        T.assert_particles_equal(sim.download_aos(), T.oracle_gen_filled_aos(0, n), f"filled {n}")
+
+
+def test_default_configuration_of_the_app():
+    """The app's compute-backend start: 1 M particles, hollow sphere (app.rs:103,117),
+    then frames with the default UI values and the attractor held (app.rs:143-148)."""
+    n = 1_000_000
+    params = T.bench_params()
+    with Sim.new(n, psim.GEN_HOLLOW) as sim:
+        start = sim.download_aos()
+        for _ in range(20):
+            sim.update(params)
+        got = sim.download_aos()
+    T.assert_particles_equal(got, T.oracle_update_aos(start, params, 20), "1M hollow x 20")
+
+
+# ---- resize / reset (compute-backend semantics, compute.rs:146-216) ---------------------------
+
+def test_resize_regenerates_everything():
+    with Sim.new(5000, psim.GEN_HOLLOW) as sim:
+        for _ in range(3):
+            sim.update(T.bench_params(gravity=2.0))
+        sim.resize_buffer(5000, psim.GEN_HOLLOW)              # equal count: no-op
+        assert sim.download_aos().tobytes() != T.oracle_gen_hollow_aos(5000).tobytes()
+        sim.resize_buffer(20_000, psim.GEN_HOLLOW)            # grow: fresh state
+        assert sim.get_particle_count() == 20_000
+        T.assert_particles_equal(sim.download_aos(), T.oracle_gen_hollow_aos(20_000), "grown")
+        sim.update(T.bench_params(gravity=2.0))
+        sim.resize_buffer(300, psim.GEN_FILLED)               # shrink: fresh state, new mode
+        assert sim.get_particle_count() == 300
+        T.assert_particles_equal(sim.download_aos(), T.oracle_gen_filled_aos(0, 300), "shrunk")
+        view = sim.get_particle_buffer()
+        assert view.count == 300 and view.capacity >= 20_000  # storage kept on shrink
+
+
+def test_reset_regenerates_current_count():
+    with Sim.new(7777, psim.GEN_UNIFORM) as sim:
+        for _ in range(2):
+            sim.update(T.bench_params())
+        sim.reset(psim.GEN_HOLLOW)
+        assert sim.get_particle_count() == 7777
+        T.assert_particles_equal(sim.download_aos(), T.oracle_gen_hollow_aos(7777), "reset")
+        sim.reset(psim.GEN_UNIFORM)
+        T.assert_particles_equal(sim.download_aos(), T.oracle_gen_uniform_aos(0, 7777), "reset u")
+
+
+# ---- AoS import / export ----------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 10_000])
+def test_aos_round_trip_keeps_all_64_bytes(n):
+    p = random_particles(n, n)
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        sim.upload_aos(p)
+        assert sim.download_aos().tobytes() == p.tobytes()
+        # partial ranges
+        if n >= 257:
+            part = random_particles(100, 5)
+            sim.upload_aos(part, first=130)
+            p[130:230] = part
+            assert sim.download_aos().tobytes() == p.tobytes()
+            assert sim.download_aos(200, 57).tobytes() == p[200:257].tobytes()
+        soa = sim.download_soa()
+        T.assert_same_f32(soa, T.aos_to_soa(p), "soa view of uploaded data")
+
+
+def test_soa_upload_download():
+    n = 5000
+    soa = np.random.default_rng(3).uniform(-9, 9, size=(6, n)).astype(np.float32)
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        sim.upload_soa(soa)
+        assert sim.download_soa().tobytes() == soa.tobytes()
+        sim.upload_soa(soa[:, :100] * 2, first=50)
+        soa[:, 50:150] = soa[:, :100] * 2
+        assert sim.download_soa().tobytes() == soa.tobytes()
+        assert sim.download_soa(40, 20).tobytes() == np.ascontiguousarray(soa[:, 40:60]).tobytes()
+
+
+def test_device_side_export_import():
+    """Export into a device AoS buffer (as a renderer's vertex buffer would be) and
+    import it into a second simulation."""
+    n = 3000
+    p = random_particles(n, 9)
+    with Sim.new(n, psim.GEN_UNIFORM) as a, Sim.new(n, psim.GEN_UNIFORM) as b, \
+            Sim.new(16 * n, psim.GEN_UNIFORM) as scratch:
+        a.upload_aos(p)
+        buf = scratch.get_particle_buffer().color              # n * 64 B of device memory
+        a.export_aos_device(buf)
+        a.sync()
+        b.import_aos_device(buf)
+        assert b.download_aos().tobytes() == p.tobytes()
+
+
+def test_paddings_and_initial_colour_survive_updates():
+    n = 2048
+    p = random_particles(n, 11)
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        sim.upload_aos(p)
+        for mode in (0, 1, 2):
+            sim.update(T.bench_params(color_mode=mode))
+        out = sim.download_aos()
+    for f in ("padding1", "padding2", "initial_color"):
+        assert out[f].tobytes() == p[f].tobytes()
+
+
+# ---- shards --------------------------------------------------------------------------------------
+
+def test_shards_tile_the_global_array():
+    total = 100_003
+    params = T.bench_params(mouse_radius=50.0)
+    cuts = [0, 25_000, 25_001, 70_000, total]
+    with Sim.new(total, psim.GEN_UNIFORM) as whole:
+        for _ in range(3):
+            whole.update(params)
+        ref = whole.download_aos()
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        with Sim.new_shard(hi - lo, lo, total, psim.GEN_UNIFORM) as shard:
+            for _ in range(3):
+                shard.update(params)
+            assert shard.download_aos().tobytes() == ref[lo:hi].tobytes()
+
+
+@pytest.mark.parametrize("mode", [psim.GEN_HOLLOW, psim.GEN_FILLED])
+def test_reference_generators_shard_consistently(mode):
+    total = 10_000
+    with Sim.new(total, mode) as whole:
+        ref = whole.download_aos()
+    with Sim.new_shard(3000, 6000, total, mode) as shard:
+        assert shard.download_aos().tobytes() == ref[6000:9000].tobytes()
+
+
+def test_uniform_shard_beyond_u32_indices():
+    first = 5_000_000_000
+    with Sim.new_shard(1000, first, 8_000_000_000, psim.GEN_UNIFORM) as shard:
+        T.assert_particles_equal(shard.download_aos(), T.oracle_gen_uniform_aos(first, 1000),
+                                 "shard past 2^32")
+
+
+# ---- errors -----------------------------------------------------------------------------------------
+
+def test_error_codes():
+    lib = psim.load_library()
+    h = ctypes.c_void_p()
+    assert lib.psim_create(ctypes.byref(h), 10, psim.GEN_UNIFORM, 9999) == 1
+    assert b"out of range" in lib.psim_last_error()
+    with Sim.new(100, psim.GEN_UNIFORM) as sim:
+        with pytest.raises(psim.PsimError) as e:
+            sim.download_aos(50, 51)
+        assert e.value.code == 1
+        with pytest.raises(psim.PsimError):
+            sim.resize_buffer(10, 42)
+        with pytest.raises(psim.PsimError):
+            sim.update_multi(T.bench_params(), np.zeros(9, dtype=psim.ATTRACTOR_DTYPE))
+        with pytest.raises(psim.PsimError):
+            sim.update_multi_device(T.bench_params(), 0, 3)
+        with pytest.raises(psim.PsimError):
+            sim.update_multi_device(T.bench_params(), sim.get_particle_buffer().color, 65)
+    with Sim.new_shard(10, 0, 100, psim.GEN_UNIFORM) as shard:
+        with pytest.raises(psim.PsimError, match="shard"):
+            shard.resize_buffer(20, psim.GEN_UNIFORM)
+
+
+def test_timer_reports_device_time():
+    with Sim.new(1_000_000, psim.GEN_UNIFORM) as sim:
+        sim.timer_start()
+        for _ in range(10):
+            sim.update(T.bench_params())
+        ms = sim.timer_stop()
+        assert 0.0 < ms < 1000.0
