@@ -164,12 +164,14 @@ int psim_update_soa(float *px, float *py, float *pz, float *vx, float *vy, float
                     float *color, uint32_t count, const psim_sim_params *params,
                     void *hip_stream);
 
-/* Writes one attractor record into device memory at `dst_device` from a host
- * value, asynchronously on the handle's stream (the value travels in the kernel
- * arguments, so the host copy may be reused immediately).  Used to stage this
- * rank's attractor into the send buffer of the all-gather. */
-int psim_store_attractor(psim_handle *h, psim_attractor *dst_device,
-                         const psim_attractor *value_host);
+/* Writes one attractor record into device memory at `dst_device` (4-byte
+ * aligned, on the current device) from a host value, asynchronously on
+ * `hip_stream` (null = the default stream).  The value travels in the kernel
+ * arguments, so the host copy may be reused immediately and no pinned memory is
+ * needed.  Used to stage this rank's attractor into the send buffer of the
+ * all-gather on the communication stream. */
+int psim_store_attractor(psim_attractor *dst_device, const psim_attractor *value_host,
+                         void *hip_stream);
 
 /* Blocks until everything enqueued on the handle's stream has finished.  The
  * reference's equivalent is the caller's queue.submit + present (src/app.rs:313). */

@@ -1,0 +1,154 @@
+// psim.hpp -- C++ host-side mirror of the reference's `trait ParticleSimulation`
+// (reference: src/simulation/mod.rs:21-50) over the C ABI of psim.h.
+//
+// Method names and argument meaning follow the trait; the wgpu device / queue /
+// encoder / surface-format arguments are dropped.  Like the reference's methods
+// (which return nothing and abort on a wgpu validation failure), the methods here do
+// not return status codes: a failing call throws psim::Error carrying the C ABI's
+// status and message.  Header-only; link against libpsim_hip.so.
+#ifndef PSIM_HPP
+#define PSIM_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "psim.h"
+
+namespace psim {
+
+// `enum SimulationMethod` (mod.rs:9-13) plus this backend.
+enum class SimulationMethod { Cpu = PSIM_METHOD_CPU, ComputeShader = PSIM_METHOD_COMPUTE_SHADER,
+                              Hip = PSIM_METHOD_HIP };
+
+// `enum SphereGeneration` (mod.rs:15-19) plus the synthetic benchmark state.
+enum class SphereGeneration { Hollow = PSIM_GEN_HOLLOW, Filled = PSIM_GEN_FILLED,
+                              Uniform = PSIM_GEN_UNIFORM };
+
+using SimParams = psim_sim_params;   // mod.rs:52-67
+using Particle = psim_particle;      // mod.rs:86-98
+using Attractor = psim_attractor;
+
+// `impl Default for SimParams` (mod.rs:69-84).
+inline SimParams default_sim_params()
+{
+    SimParams p{};
+    p.delta_time = 0.016f;
+    p.gravity = 0.0f;
+    p.color_mode = 0;
+    p.mouse_force = 5.0f;
+    p.mouse_radius = 10.0f;
+    p.is_mouse_dragging = 0;
+    p.damping = 0.99f;
+    p.max_dist_for_color = 50.0f;
+    p.mouse_position[0] = p.mouse_position[1] = p.mouse_position[2] = 0.0f;
+    p._padding2 = 0;
+    return p;
+}
+
+class Error : public std::runtime_error {
+public:
+    Error(int code, const std::string &what) : std::runtime_error(what), code_(code) {}
+    int code() const { return code_; }
+
+private:
+    int code_;
+};
+
+class HipParticleSimulation {
+public:
+    // `fn new(device, initial_particle_count, surface_format, generation_mode) -> Self`
+    HipParticleSimulation(uint32_t initial_particle_count, SphereGeneration generation_mode,
+                          int device_id = 0)
+    {
+        check(psim_create(&h_, initial_particle_count, static_cast<int>(generation_mode),
+                          device_id));
+    }
+
+    // One shard [global_first, global_first + count) of a `global_count` set.
+    HipParticleSimulation(uint32_t count, uint64_t global_first, uint64_t global_count,
+                          SphereGeneration generation_mode, int device_id)
+    {
+        check(psim_create_shard(&h_, count, global_first, global_count,
+                                static_cast<int>(generation_mode), device_id));
+    }
+
+    ~HipParticleSimulation() { psim_destroy(h_); }
+    HipParticleSimulation(const HipParticleSimulation &) = delete;
+    HipParticleSimulation &operator=(const HipParticleSimulation &) = delete;
+    HipParticleSimulation(HipParticleSimulation &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+
+    // `fn update(&mut self, device, queue, encoder, params: &SimParams)`: asynchronous.
+    void update(const SimParams &params) { check(psim_update(h_, &params)); }
+
+    // Multi-attractor extension, list in host memory (<= 8) or device memory (<= 64).
+    void update_multi(const SimParams &params, const std::vector<Attractor> &attractors)
+    {
+        check(psim_update_multi_host(h_, &params, attractors.data(),
+                                     static_cast<uint32_t>(attractors.size())));
+    }
+    void update_multi_device(const SimParams &params, const Attractor *attractors_device,
+                             uint32_t n)
+    {
+        check(psim_update_multi(h_, &params, attractors_device, n));
+    }
+
+    void sync() { check(psim_sync(h_)); }
+
+    // `fn resize_buffer(&mut self, device, queue, new_count, generation_mode)`
+    void resize_buffer(uint32_t new_count, SphereGeneration generation_mode)
+    {
+        check(psim_resize(h_, new_count, static_cast<int>(generation_mode)));
+    }
+
+    // `fn get_particle_buffer(&self) -> &wgpu::Buffer`: the device arrays.
+    psim_soa_view get_particle_buffer()
+    {
+        psim_soa_view v{};
+        check(psim_device_soa(h_, &v));
+        return v;
+    }
+
+    // `fn get_method(&self) -> SimulationMethod`
+    SimulationMethod get_method() const { return static_cast<SimulationMethod>(psim_method(h_)); }
+
+    // `fn get_particle_count(&self) -> u32`
+    uint32_t get_particle_count() const { return psim_particle_count(h_); }
+
+    // `fn reset(&mut self, device, queue, generation_mode)`
+    void reset(SphereGeneration generation_mode)
+    {
+        check(psim_reset(h_, static_cast<int>(generation_mode)));
+    }
+
+    // `fn is_paused(&self) -> bool` / `fn set_paused(&mut self, paused: bool)`
+    bool is_paused() const { return psim_is_paused(h_) != 0; }
+    void set_paused(bool paused) { psim_set_paused(h_, paused ? 1 : 0); }
+
+    // The reference's 64-byte records, to and from host memory.
+    std::vector<Particle> download()
+    {
+        std::vector<Particle> out(get_particle_count());
+        check(psim_download_aos(h_, out.data(), 0, out.size()));
+        return out;
+    }
+    void upload(const std::vector<Particle> &particles, uint64_t first = 0)
+    {
+        check(psim_upload_aos(h_, particles.data(), first, particles.size()));
+    }
+
+    psim_handle *handle() { return h_; }
+
+private:
+    static void check(int rc)
+    {
+        if (rc != PSIM_OK) throw Error(rc, psim_last_error());
+    }
+    psim_handle *h_ = nullptr;
+};
+
+}  // namespace psim
+
+#endif  // PSIM_HPP

@@ -244,10 +244,11 @@ class HipParticleSimulation:
         _check(self._lib.psim_update_multi_host(self._h, byref(params),
                                                 arr.ctypes.data_as(c_void_p), len(arr)))
 
-    def store_attractor(self, dst_device_ptr, attractor):
-        arr = _as_attractors(attractor).reshape(-1)[:1]
-        _check(self._lib.psim_store_attractor(self._h, c_void_p(dst_device_ptr),
-                                              arr.ctypes.data_as(c_void_p)))
+    def store_attractor(self, dst_device_ptr, attractor, stream=None):
+        """Writes one attractor record to device memory on `stream` (default: the
+        handle's stream)."""
+        store_attractor(dst_device_ptr, attractor,
+                        self.get_stream() if stream is None else stream)
 
     def sync(self):
         _check(self._lib.psim_sync(self._h))
@@ -350,6 +351,13 @@ def update_soa(px, py, pz, vx, vy, vz, color, count, params, stream=0):
     _check(lib.psim_update_soa(c_void_p(px), c_void_p(py), c_void_p(pz), c_void_p(vx),
                                c_void_p(vy), c_void_p(vz), c_void_p(color), count,
                                byref(params), c_void_p(stream)))
+
+
+def store_attractor(dst_device_ptr, attractor, stream=0):
+    """Writes one ATTRACTOR_DTYPE record to DEVICE memory, asynchronously on `stream`."""
+    arr = _as_attractors(attractor).reshape(-1)[:1]
+    _check(load_library().psim_store_attractor(c_void_p(dst_device_ptr),
+                                               arr.ctypes.data_as(c_void_p), c_void_p(stream)))
 
 
 def version():

@@ -80,7 +80,7 @@ struct psim_handle {
     psim_attractor *attr_stage_dev = nullptr;  // PSIM_MAX_ATTRACTORS records inside the slab
     psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    psim::LaunchTuning tuning = {0, 1, 1};
+    psim::LaunchTuning tuning = {0, 3, 1, 0};
 };
 
 namespace {
@@ -320,8 +320,9 @@ int create_impl(psim_handle **out, uint32_t count, uint64_t global_first, uint64
     h->global_count = global_count;
     h->generation_mode = generation_mode;
     h->tuning.max_blocks = (uint32_t)env_int("PSIM_MAX_BLOCKS", 0);
-    h->tuning.nontemporal = env_int("PSIM_NT", 1);
+    h->tuning.nontemporal = env_int("PSIM_NT", 3);
     h->tuning.unroll = env_int("PSIM_UNROLL", 1);
+    h->tuning.dynamic_lds = (uint32_t)env_int("PSIM_DYN_LDS", 0);
     int rc = PSIM_OK;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -434,8 +435,8 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
     const bool vec = aligned16(px) && aligned16(py) && aligned16(pz) && aligned16(vx) &&
                      aligned16(vy) && aligned16(vz) && (!colours || aligned16(color));
     if (vec) {
-        psim::LaunchTuning t = {(uint32_t)env_int("PSIM_MAX_BLOCKS", 0), env_int("PSIM_NT", 1),
-                                env_int("PSIM_UNROLL", 1)};
+        psim::LaunchTuning t = {(uint32_t)env_int("PSIM_MAX_BLOCKS", 0), env_int("PSIM_NT", 3),
+                                env_int("PSIM_UNROLL", 1), 0};
         HIP_TRY(psim::launch_update(s, count, *params, params->is_mouse_dragging > 0 ? 1 : 0,
                                     nullptr, nullptr, 0, t, stream));
     } else {
@@ -446,12 +447,14 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
     return PSIM_OK;
 }
 
-PSIM_API int psim_store_attractor(psim_handle *h, psim_attractor *dst_device,
-                                  const psim_attractor *value_host)
+PSIM_API int psim_store_attractor(psim_attractor *dst_device, const psim_attractor *value_host,
+                                  void *hip_stream)
 {
-    CHECK_HANDLE(h);
     if (!dst_device || !value_host) return fail(PSIM_ERR_INVALID, "null attractor pointer");
-    HIP_TRY(psim::launch_store_attractor(dst_device, *value_host, h->stream));
+    if (reinterpret_cast<uintptr_t>(dst_device) & 3u)
+        return fail(PSIM_ERR_INVALID, "attractor destination must be 4-byte aligned");
+    HIP_TRY(psim::launch_store_attractor(dst_device, *value_host,
+                                         static_cast<hipStream_t>(hip_stream)));
     return PSIM_OK;
 }
 

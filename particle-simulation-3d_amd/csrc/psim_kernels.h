@@ -24,8 +24,9 @@ struct SoaPtrs {
 // Launch shape of the update kernel.
 struct LaunchTuning {
     uint32_t max_blocks;   // 0 = one pass (grid covers every group), else grid-stride cap
-    int nontemporal;       // non-temporal loads/stores
+    int nontemporal;       // bit 0: non-temporal loads, bit 1: non-temporal stores
     int unroll;            // float4 groups per lane per trip: 1 or 2
+    uint32_t dynamic_lds;  // unused dynamic LDS bytes per workgroup (caps waves per CU)
 };
 
 uint32_t update_grid(uint32_t n, const LaunchTuning &t);

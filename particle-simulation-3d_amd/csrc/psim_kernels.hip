@@ -127,13 +127,14 @@ struct KernargAttractors {
 //
 // CM    colour mode 0 (colour untouched, 48 B/particle), 1 or 2 (+16 B store).
 // FORCE see step().
-// NT    non-temporal loads and stores (the state is streamed once per step).
+// NT    bit 0: non-temporal loads, bit 1: non-temporal stores (the state is
+//       streamed once per step, so neither side profits from staying in cache).
 // U     float4 groups per lane per loop trip (U*4 particles, 6*U loads in flight).
 //
 // Grid-stride over groups of 4 consecutive particles; a launch whose grid covers
 // every group runs the loop once.  The last n % 4 particles are stepped one at a
 // time by workgroup 0.
-template <int CM, int FORCE, bool NT, int U>
+template <int CM, int FORCE, int NT, int U>
 __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t n,
                                                            psim_sim_params p,
                                                            const psim_attractor *attr_dev,
@@ -168,8 +169,8 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t 
         for (int k = 0; k < U; ++k) {
             const uint32_t g = g0 + k * stride;
             if (g < ngroups) {
-                x[k] = ld<NT>(px4 + g); y[k] = ld<NT>(py4 + g); z[k] = ld<NT>(pz4 + g);
-                u[k] = ld<NT>(vx4 + g); v[k] = ld<NT>(vy4 + g); w[k] = ld<NT>(vz4 + g);
+                x[k] = ld<(NT & 1) != 0>(px4 + g); y[k] = ld<(NT & 1) != 0>(py4 + g); z[k] = ld<(NT & 1) != 0>(pz4 + g);
+                u[k] = ld<(NT & 1) != 0>(vx4 + g); v[k] = ld<(NT & 1) != 0>(vy4 + g); w[k] = ld<(NT & 1) != 0>(vz4 + g);
             }
         }
 #pragma unroll
@@ -184,12 +185,12 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t 
                     x[k][j] = a; y[k][j] = b; z[k][j] = c;
                     u[k][j] = d; v[k][j] = e; w[k][j] = f;
                 }
-                st<NT>(px4 + g, x[k]); st<NT>(py4 + g, y[k]); st<NT>(pz4 + g, z[k]);
-                st<NT>(vx4 + g, u[k]); st<NT>(vy4 + g, v[k]); st<NT>(vz4 + g, w[k]);
+                st<(NT & 2) != 0>(px4 + g, x[k]); st<(NT & 2) != 0>(py4 + g, y[k]); st<(NT & 2) != 0>(pz4 + g, z[k]);
+                st<(NT & 2) != 0>(vx4 + g, u[k]); st<(NT & 2) != 0>(vy4 + g, v[k]); st<(NT & 2) != 0>(vz4 + g, w[k]);
                 if constexpr (CM != 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        st<NT>(col4 + 4ull * g + j,
+                        st<(NT & 2) != 0>(col4 + 4ull * g + j,
                                colour<CM>(x[k][j], y[k][j], z[k][j], u[k][j], v[k][j], w[k][j], p));
                 }
             }
@@ -229,13 +230,14 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel_scalar(SoaPtrs s, ui
 
 // ---- launch dispatch -------------------------------------------------------
 
-template <int CM, int FORCE, bool NT, int U>
+template <int CM, int FORCE, int NT, int U>
 static hipError_t launch_one(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
                              const psim_attractor *attr_dev, uint32_t na,
-                             const KernargAttractors &ka, uint32_t grid, hipStream_t stream)
+                             const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
+                             hipStream_t stream)
 {
-    hipLaunchKernelGGL((update_kernel<CM, FORCE, NT, U>), dim3(grid), dim3(PSIM_BLOCK), 0, stream,
-                       s, n, p, attr_dev, na, ka);
+    hipLaunchKernelGGL((update_kernel<CM, FORCE, NT, U>), dim3(grid), dim3(PSIM_BLOCK),
+                       t.dynamic_lds, stream, s, n, p, attr_dev, na, ka);
     return hipGetLastError();
 }
 
@@ -245,12 +247,15 @@ static hipError_t launch_nt_u(const SoaPtrs &s, uint32_t n, const psim_sim_param
                               const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
                               hipStream_t stream)
 {
-    if (t.nontemporal) {
-        if (t.unroll >= 2) return launch_one<CM, FORCE, true, 2>(s, n, p, attr_dev, na, ka, grid, stream);
-        return launch_one<CM, FORCE, true, 1>(s, n, p, attr_dev, na, ka, grid, stream);
+#define PSIM_LAUNCH(NT, U) launch_one<CM, FORCE, NT, U>(s, n, p, attr_dev, na, ka, t, grid, stream)
+    const bool two = t.unroll >= 2;
+    switch (t.nontemporal & 3) {
+    case 0: return two ? PSIM_LAUNCH(0, 2) : PSIM_LAUNCH(0, 1);
+    case 1: return two ? PSIM_LAUNCH(1, 2) : PSIM_LAUNCH(1, 1);
+    case 2: return two ? PSIM_LAUNCH(2, 2) : PSIM_LAUNCH(2, 1);
+    default: return two ? PSIM_LAUNCH(3, 2) : PSIM_LAUNCH(3, 1);
     }
-    if (t.unroll >= 2) return launch_one<CM, FORCE, false, 2>(s, n, p, attr_dev, na, ka, grid, stream);
-    return launch_one<CM, FORCE, false, 1>(s, n, p, attr_dev, na, ka, grid, stream);
+#undef PSIM_LAUNCH
 }
 
 template <int FORCE>

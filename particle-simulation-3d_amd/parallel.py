@@ -1,0 +1,148 @@
+"""Sharding of the particle array across the GPUs of one node, one process per GPU.
+
+Particles never read other particles (reference: src/simulation/cpu.rs:65-113 has no
+pairwise term), so the array is cut into contiguous index ranges and every rank steps
+its own range.  With the reference's single attractor the 48-byte SimParams is
+replicated by the host and NO communication happens.  Only the multi-attractor
+extension (one moving attractor owned by each rank; the reference has exactly one)
+exchanges data: a 32-byte record per rank per step, all-gathered with
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in CPU tests).
+The exchange is latency-bound (256 B on 8 ranks), so it runs on its own stream into a
+double-buffered receive array and overlaps the previous step's kernel.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import ATTRACTOR_DTYPE, GEN_UNIFORM, HipParticleSimulation, store_attractor
+
+ATTRACTOR_FLOATS = ATTRACTOR_DTYPE.itemsize // 4      # 8 four-byte words per record
+
+
+def shard_range(total, rank, world):
+    """Contiguous range of rank `rank`: (first, count).  Ranges tile [0, total) and
+    differ in size by at most one particle."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    first = rank * total // world
+    last = (rank + 1) * total // world
+    return first, last - first
+
+
+def attractor_at(step, index, force=5.0, radius=10.0):
+    """Attractor `index` at step `step`: a closed-form Lissajous path inside the
+    50-unit world cube (evaluated in float64, rounded once to fp32), so every rank and
+    the CPU oracle can reproduce any attractor at any step without communication."""
+    t = 0.01 * step
+    a = np.zeros(1, dtype=ATTRACTOR_DTYPE)
+    a["position"][0] = (
+        40.0 * math.sin((1.0 + 0.25 * index) * t + 0.7 * index),
+        40.0 * math.sin((1.5 + 0.125 * index) * t + 1.3 * index),
+        40.0 * math.cos((0.75 + 0.0625 * index) * t + 0.4 * index),
+    )
+    a["force"] = force
+    a["radius"] = radius
+    a["active"] = 1
+    return a
+
+
+def attractors_at(step, world, force=5.0, radius=10.0):
+    """All `world` attractors at `step` (what the all-gather must deliver)."""
+    return np.concatenate([attractor_at(step, i, force, radius) for i in range(world)])
+
+
+class AttractorExchange:
+    """All-gather of one attractor record per rank with torch.distributed.
+
+    Backend-agnostic: tensors live on `device` ("cpu" with gloo, "cuda" with nccl).
+    `gather(record)` returns a (world, 8) float32 tensor holding every rank's record
+    bit for bit (the uint32 `active` word travels as its float32 bit pattern).
+    """
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = device
+
+    def gather(self, record):
+        torch, dist = self._torch, self._dist
+        words = np.ascontiguousarray(record, dtype=ATTRACTOR_DTYPE).view(np.float32).reshape(-1)
+        send = torch.from_numpy(words.copy()).to(self.device)
+        if self.device == "cpu" or str(self.device) == "cpu":
+            parts = [torch.empty_like(send) for _ in range(self.world)]
+            dist.all_gather(parts, send, group=self._group)      # gloo
+            return torch.stack(parts)
+        recv = torch.empty(self.world * ATTRACTOR_FLOATS, dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(recv, send, group=self._group)
+        return recv.view(self.world, ATTRACTOR_FLOATS)
+
+
+def gathered_to_records(gathered):
+    """(world, 8) float32 tensor -> ATTRACTOR_DTYPE array (bit-preserving)."""
+    arr = np.ascontiguousarray(gathered.detach().cpu().numpy(), dtype=np.float32)
+    return arr.view(ATTRACTOR_DTYPE).reshape(-1)
+
+
+class MultiAttractorRunner:
+    """One rank of the sharded multi-attractor simulation on a GPU.
+
+    Per step t (buffers indexed t % 2):
+      comm stream    : wait until the kernel of step t-2 has read recv[t%2];
+                       write this rank's attractor(t) into send[t%2] (value carried in
+                       kernel arguments: no host synchronisation, no pinned memory);
+                       all-gather send[t%2] -> recv[t%2]
+      compute stream : wait for that all-gather; multi-attractor update kernel reading
+                       recv[t%2] (staged into LDS by every workgroup)
+    so the all-gather of step t+1 overlaps the kernel of step t.
+    """
+
+    def __init__(self, particles_per_rank, rank, world, local_rank, params, group=None,
+                 force=5.0, radius=10.0):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self.rank, self.world, self.params = rank, world, params
+        self.force, self.radius = force, radius
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised (backend nccl)")
+        self.sim = HipParticleSimulation.new_shard(
+            particles_per_rank, rank * particles_per_rank, world * particles_per_rank,
+            GEN_UNIFORM, device_id=local_rank)
+        dev = torch.device("cuda", local_rank)
+        self.comm = torch.cuda.Stream(device=dev)
+        self.compute = torch.cuda.Stream(device=dev)
+        self.sim.set_stream(self.compute.cuda_stream)
+        self.send = [torch.zeros(ATTRACTOR_FLOATS, dtype=torch.float32, device=dev)
+                     for _ in range(2)]
+        self.recv = [torch.zeros(world * ATTRACTOR_FLOATS, dtype=torch.float32, device=dev)
+                     for _ in range(2)]
+        self.gathered = [torch.cuda.Event() for _ in range(2)]
+        self.kernel_done = [None, None]
+        self.t = 0
+
+    def step(self):
+        torch, dist = self._torch, self._dist
+        b = self.t % 2
+        with torch.cuda.stream(self.comm):
+            if self.kernel_done[b] is not None:
+                self.comm.wait_event(self.kernel_done[b])
+            store_attractor(self.send[b].data_ptr(),
+                            attractor_at(self.t, self.rank, self.force, self.radius),
+                            self.comm.cuda_stream)
+            dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self._group)
+            self.gathered[b].record(self.comm)
+        self.compute.wait_event(self.gathered[b])
+        self.sim.update_multi_device(self.params, self.recv[b].data_ptr(), self.world)
+        ev = torch.cuda.Event()
+        ev.record(self.compute)
+        self.kernel_done[b] = ev
+        self.t += 1
+
+    def finish(self):
+        self.compute.synchronize()
+        self.comm.synchronize()

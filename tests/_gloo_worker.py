@@ -1,0 +1,61 @@
+"""Worker of tests/test_sharding_gloo.py: one rank of a world_size-N gloo job on CPU.
+
+Exercises the host logic of the sharded path -- shard ranges, closed-form attractor
+paths, the per-step all-gather of one attractor record per rank -- with the CPU oracle
+standing in for the device kernel (this is a test; the shipped path has no CPU mode).
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import psim_testlib as T  # noqa: E402
+
+par = importlib.import_module("particle-simulation-3d_amd.parallel")
+
+
+def main():
+    total, steps, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    first, count = par.shard_range(total, rank, world)
+    params = T.bench_params(gravity=0.5, is_mouse_dragging=0)
+
+    # every rank's range, to check the tiling
+    ranges = [None] * world
+    dist.all_gather_object(ranges, (first, count))
+    assert ranges[0][0] == 0 and sum(c for _, c in ranges) == total
+    for (f0, c0), (f1, _) in zip(ranges[:-1], ranges[1:]):
+        assert f0 + c0 == f1
+
+    exchange = par.AttractorExchange("cpu")
+    shard = T.oracle_gen_uniform_aos(first, count)
+    for t in range(steps):
+        mine = par.attractor_at(t, rank, force=60.0, radius=30.0)
+        gathered = par.gathered_to_records(exchange.gather(mine))
+        want = par.attractors_at(t, world, force=60.0, radius=30.0)
+        assert gathered.tobytes() == want.tobytes(), f"rank {rank} step {t}: gather mismatch"
+        shard = T.oracle_update_aos(shard, params, 1, gathered)
+
+    # collect the shards on rank 0 and compare with the unsharded run
+    blobs = [None] * world
+    dist.gather_object(shard.tobytes(), blobs if rank == 0 else None, dst=0)
+    if rank == 0:
+        got = np.frombuffer(b"".join(blobs), dtype=T.psim.PARTICLE_DTYPE)
+        whole = T.oracle_gen_uniform_aos(0, total)
+        for t in range(steps):
+            whole = T.oracle_update_aos(whole, params, 1,
+                                        par.attractors_at(t, world, force=60.0, radius=30.0))
+        assert got.tobytes() == whole.tobytes(), "sharded result differs from the whole array"
+        with open(out_path, "w") as f:
+            f.write(f"OK world={world} total={total} steps={steps}\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

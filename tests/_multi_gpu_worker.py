@@ -1,0 +1,49 @@
+"""Worker of tests/test_gpu_multi.py: the sharded multi-attractor runner on the GPU,
+torch.distributed backend nccl (= RCCL).  torch is imported before the C-ABI library so
+both share one HIP runtime."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import psim_testlib as T  # noqa: E402
+
+par = importlib.import_module("particle-simulation-3d_amd.parallel")
+
+
+def main():
+    n, steps, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    params = T.bench_params(gravity=0.5, is_mouse_dragging=0)
+    runner = par.MultiAttractorRunner(n, rank, world, local_rank, params, force=60.0, radius=30.0)
+    for _ in range(steps):
+        runner.step()
+    runner.finish()
+    got = runner.sim.download_aos()
+
+    want = T.oracle_gen_uniform_aos(rank * n, n)
+    for t in range(steps):
+        want = T.oracle_update_aos(want, params, 1,
+                                   par.attractors_at(t, world, force=60.0, radius=30.0))
+    T.assert_particles_equal(got, want, f"rank {rank}")
+    # the exchange helper on device tensors
+    ex = par.AttractorExchange(torch.device("cuda", local_rank))
+    g = par.gathered_to_records(ex.gather(par.attractor_at(3, rank)))
+    assert g.tobytes() == par.attractors_at(3, world).tobytes()
+    runner.sim.close()
+    dist.barrier(device_ids=[local_rank])
+    dist.destroy_process_group()
+    if rank == 0:
+        with open(out_path, "w") as f:
+            f.write(f"OK world={world} n={n} steps={steps}\n")
+
+
+if __name__ == "__main__":
+    main()

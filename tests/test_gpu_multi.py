@@ -1,0 +1,30 @@
+"""GPU test of the sharded multi-attractor runner: per-step all-gather over RCCL on its
+own stream, double-buffered, feeding the LDS-staged multi-attractor kernel.  One rank
+here (a single-GPU box); the world_size > 1 host logic is covered on CPU over gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import psim_testlib as T
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(T.ROOT, "tests", "_multi_gpu_worker.py")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_multi_attractor_runner_single_rank(tmp_path):
+    out = tmp_path / "result.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-u", WORKER, "300007", "12", str(out)], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert out.read_text().startswith("OK world=1")
