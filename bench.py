@@ -101,8 +101,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this benchmark has no CPU path")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.workload == "multi"
     if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():

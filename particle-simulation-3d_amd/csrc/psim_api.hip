@@ -61,6 +61,32 @@ int env_int(const char *name, int dflt)
     return atoi(v);
 }
 
+// Optional overrides of the measured launch shape (experiments only): each is
+// read from the environment when a handle is created; -1 / unset = automatic.
+struct TuningOverrides {
+    int nontemporal = -1;   // PSIM_NT           0 | 1
+    int reserve_lds = -1;   // PSIM_RESERVE_LDS  bytes of LDS reserved per workgroup
+    int max_blocks = -1;    // PSIM_MAX_BLOCKS   grid cap (0 = one pass)
+};
+
+TuningOverrides read_overrides()
+{
+    TuningOverrides o;
+    o.nontemporal = env_int("PSIM_NT", -1);
+    o.reserve_lds = env_int("PSIM_RESERVE_LDS", -1);
+    o.max_blocks = env_int("PSIM_MAX_BLOCKS", -1);
+    return o;
+}
+
+psim::LaunchTuning tuning_for(uint32_t n, const TuningOverrides &o)
+{
+    psim::LaunchTuning t = psim::choose_tuning(n);
+    if (o.nontemporal >= 0) t.nontemporal = o.nontemporal ? 1 : 0;
+    if (o.reserve_lds >= 0) t.reserve_lds = (uint32_t)o.reserve_lds;
+    if (o.max_blocks >= 0) t.max_blocks = (uint32_t)o.max_blocks;
+    return t;
+}
+
 }  // namespace
 
 struct psim_handle {
@@ -77,10 +103,9 @@ struct psim_handle {
     void *slab = nullptr;        // one allocation, carved into `soa`
     psim::SoaPtrs soa = {};
     uint64_t *checksum_dev = nullptr;          // 8 x u64 inside the slab
-    psim_attractor *attr_stage_dev = nullptr;  // PSIM_MAX_ATTRACTORS records inside the slab
     psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    psim::LaunchTuning tuning = {0, 3, 1, 0};
+    TuningOverrides overrides;
 };
 
 namespace {
@@ -120,7 +145,6 @@ int allocate(psim_handle *h, uint32_t capacity)
     h->soa.padding = reinterpret_cast<float *>(b);
     b += cap * 8;
     h->checksum_dev = reinterpret_cast<uint64_t *>(b);
-    h->attr_stage_dev = reinterpret_cast<psim_attractor *>(b + 256);
     h->capacity = capacity;
     return PSIM_OK;
 }
@@ -319,10 +343,7 @@ int create_impl(psim_handle **out, uint32_t count, uint64_t global_first, uint64
     h->global_first = global_first;
     h->global_count = global_count;
     h->generation_mode = generation_mode;
-    h->tuning.max_blocks = (uint32_t)env_int("PSIM_MAX_BLOCKS", 0);
-    h->tuning.nontemporal = env_int("PSIM_NT", 3);
-    h->tuning.unroll = env_int("PSIM_UNROLL", 1);
-    h->tuning.dynamic_lds = (uint32_t)env_int("PSIM_DYN_LDS", 0);
+    h->overrides = read_overrides();
     int rc = PSIM_OK;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -383,7 +404,8 @@ PSIM_API int psim_update(psim_handle *h, const psim_sim_params *params)
     CHECK_HANDLE(h);
     if (!params) return fail(PSIM_ERR_INVALID, "null params");
     const int force = params->is_mouse_dragging > 0 ? 1 : 0;
-    HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, nullptr, 0, h->tuning,
+    HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, nullptr, 0,
+                                tuning_for(h->count, h->overrides),
                                 h->stream));
     return PSIM_OK;
 }
@@ -401,7 +423,7 @@ PSIM_API int psim_update_multi(psim_handle *h, const psim_sim_params *params,
         return fail(PSIM_ERR_INVALID, "attractor list must be 4-byte aligned");
     const int force = n_attractors ? 2 : 0;
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, attractors_device, nullptr,
-                                n_attractors, h->tuning, h->stream));
+                                n_attractors, tuning_for(h->count, h->overrides), h->stream));
     return PSIM_OK;
 }
 
@@ -416,7 +438,7 @@ PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *param
     if (n_attractors && !attractors_host) return fail(PSIM_ERR_INVALID, "null attractor list");
     const int force = n_attractors ? 3 : 0;
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, attractors_host,
-                                n_attractors, h->tuning, h->stream));
+                                n_attractors, tuning_for(h->count, h->overrides), h->stream));
     return PSIM_OK;
 }
 
@@ -435,8 +457,7 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
     const bool vec = aligned16(px) && aligned16(py) && aligned16(pz) && aligned16(vx) &&
                      aligned16(vy) && aligned16(vz) && (!colours || aligned16(color));
     if (vec) {
-        psim::LaunchTuning t = {(uint32_t)env_int("PSIM_MAX_BLOCKS", 0), env_int("PSIM_NT", 3),
-                                env_int("PSIM_UNROLL", 1), 0};
+        const psim::LaunchTuning t = tuning_for(count, read_overrides());
         HIP_TRY(psim::launch_update(s, count, *params, params->is_mouse_dragging > 0 ? 1 : 0,
                                     nullptr, nullptr, 0, t, stream));
     } else {

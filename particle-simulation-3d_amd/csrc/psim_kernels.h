@@ -24,12 +24,14 @@ struct SoaPtrs {
 // Launch shape of the update kernel.
 struct LaunchTuning {
     uint32_t max_blocks;   // 0 = one pass (grid covers every group), else grid-stride cap
-    int nontemporal;       // bit 0: non-temporal loads, bit 1: non-temporal stores
-    int unroll;            // float4 groups per lane per trip: 1 or 2
-    uint32_t dynamic_lds;  // unused dynamic LDS bytes per workgroup (caps waves per CU)
+    int nontemporal;       // non-temporal loads/stores of the state arrays
+    uint32_t reserve_lds;  // untouched dynamic LDS bytes per workgroup: caps workgroups per CU
 };
 
 uint32_t update_grid(uint32_t n, const LaunchTuning &t);
+
+// The measured-best launch shape for a state of n particles.
+LaunchTuning choose_tuning(uint32_t n);
 
 // force: 0 none, 1 the SimParams attractor, 2 list in device memory (staged in
 // LDS), 3 list copied from host memory into the kernel arguments.

@@ -127,14 +127,19 @@ struct KernargAttractors {
 //
 // CM    colour mode 0 (colour untouched, 48 B/particle), 1 or 2 (+16 B store).
 // FORCE see step().
-// NT    bit 0: non-temporal loads, bit 1: non-temporal stores (the state is
-//       streamed once per step, so neither side profits from staying in cache).
-// U     float4 groups per lane per loop trip (U*4 particles, 6*U loads in flight).
+// NT    non-temporal loads and stores of the six state arrays: a state larger
+//       than the 256 MiB Infinity Cache is streamed once per step, so keeping its
+//       lines cached only evicts useful ones (+3..4 % at 100 M particles); a
+//       cache-resident state (<= ~12 M particles) is faster with plain accesses.
+//       Colour stores are always plain: a lane writes 4 x 16 B at a 64 B stride
+//       per instruction, and only plain stores are merged into whole lines in L2
+//       (non-temporal colour stores ran 2.4x slower).
 //
 // Grid-stride over groups of 4 consecutive particles; a launch whose grid covers
-// every group runs the loop once.  The last n % 4 particles are stepped one at a
-// time by workgroup 0.
-template <int CM, int FORCE, int NT, int U>
+// every group runs the loop once (the fastest shape measured: workgroups are
+// dispatched in index order, so the resident ones sweep a narrow window of each
+// array).  The last n % 4 particles are stepped one at a time by workgroup 0.
+template <int CM, int FORCE, bool NT>
 __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t n,
                                                            psim_sim_params p,
                                                            const psim_attractor *attr_dev,
@@ -161,39 +166,23 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t 
 
     const uint32_t ngroups = n >> 2;
     const uint32_t stride = gridDim.x * PSIM_BLOCK;          // groups per grid pass
-    // A trip handles U groups per lane, `stride` apart, so every wave instruction
-    // still covers 1 KiB of consecutive addresses.
-    for (uint32_t g0 = blockIdx.x * PSIM_BLOCK + threadIdx.x; g0 < ngroups; g0 += stride * U) {
-        f32x4 x[U], y[U], z[U], u[U], v[U], w[U];
+    // Each wave instruction covers 1 KiB of consecutive addresses of one array.
+    for (uint32_t g = blockIdx.x * PSIM_BLOCK + threadIdx.x; g < ngroups; g += stride) {
+        f32x4 x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
+        f32x4 u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint32_t g = g0 + k * stride;
-            if (g < ngroups) {
-                x[k] = ld<(NT & 1) != 0>(px4 + g); y[k] = ld<(NT & 1) != 0>(py4 + g); z[k] = ld<(NT & 1) != 0>(pz4 + g);
-                u[k] = ld<(NT & 1) != 0>(vx4 + g); v[k] = ld<(NT & 1) != 0>(vy4 + g); w[k] = ld<(NT & 1) != 0>(vz4 + g);
-            }
+        for (int j = 0; j < 4; ++j) {
+            float a = x[j], b = y[j], c = z[j], d = u[j], e = v[j], f = w[j];
+            step<FORCE>(a, b, c, d, e, f, p, alist, na);
+            x[j] = a; y[j] = b; z[j] = c;
+            u[j] = d; v[j] = e; w[j] = f;
         }
+        st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
+        st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
+        if constexpr (CM != 0) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint32_t g = g0 + k * stride;
-            if (g < ngroups) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a = x[k][j], b = y[k][j], c = z[k][j];
-                    float d = u[k][j], e = v[k][j], f = w[k][j];
-                    step<FORCE>(a, b, c, d, e, f, p, alist, na);
-                    x[k][j] = a; y[k][j] = b; z[k][j] = c;
-                    u[k][j] = d; v[k][j] = e; w[k][j] = f;
-                }
-                st<(NT & 2) != 0>(px4 + g, x[k]); st<(NT & 2) != 0>(py4 + g, y[k]); st<(NT & 2) != 0>(pz4 + g, z[k]);
-                st<(NT & 2) != 0>(vx4 + g, u[k]); st<(NT & 2) != 0>(vy4 + g, v[k]); st<(NT & 2) != 0>(vz4 + g, w[k]);
-                if constexpr (CM != 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        st<(NT & 2) != 0>(col4 + 4ull * g + j,
-                               colour<CM>(x[k][j], y[k][j], z[k][j], u[k][j], v[k][j], w[k][j], p));
-                }
-            }
+            for (int j = 0; j < 4; ++j)
+                col4[4ull * g + j] = colour<CM>(x[j], y[j], z[j], u[j], v[j], w[j], p);
         }
     }
 
@@ -230,32 +219,21 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel_scalar(SoaPtrs s, ui
 
 // ---- launch dispatch -------------------------------------------------------
 
-template <int CM, int FORCE, int NT, int U>
-static hipError_t launch_one(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
-                             const psim_attractor *attr_dev, uint32_t na,
-                             const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
-                             hipStream_t stream)
-{
-    hipLaunchKernelGGL((update_kernel<CM, FORCE, NT, U>), dim3(grid), dim3(PSIM_BLOCK),
-                       t.dynamic_lds, stream, s, n, p, attr_dev, na, ka);
-    return hipGetLastError();
-}
-
 template <int CM, int FORCE>
-static hipError_t launch_nt_u(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
-                              const psim_attractor *attr_dev, uint32_t na,
-                              const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
-                              hipStream_t stream)
+static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
+                            const psim_attractor *attr_dev, uint32_t na,
+                            const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
+                            hipStream_t stream)
 {
-#define PSIM_LAUNCH(NT, U) launch_one<CM, FORCE, NT, U>(s, n, p, attr_dev, na, ka, t, grid, stream)
-    const bool two = t.unroll >= 2;
-    switch (t.nontemporal & 3) {
-    case 0: return two ? PSIM_LAUNCH(0, 2) : PSIM_LAUNCH(0, 1);
-    case 1: return two ? PSIM_LAUNCH(1, 2) : PSIM_LAUNCH(1, 1);
-    case 2: return two ? PSIM_LAUNCH(2, 2) : PSIM_LAUNCH(2, 1);
-    default: return two ? PSIM_LAUNCH(3, 2) : PSIM_LAUNCH(3, 1);
-    }
-#undef PSIM_LAUNCH
+    // t.reserve_lds bytes of dynamic LDS are requested but never touched: they only
+    // limit how many workgroups a CU holds at once (see choose_tuning()).
+    if (t.nontemporal)
+        hipLaunchKernelGGL((update_kernel<CM, FORCE, true>), dim3(grid), dim3(PSIM_BLOCK),
+                           t.reserve_lds, stream, s, n, p, attr_dev, na, ka);
+    else
+        hipLaunchKernelGGL((update_kernel<CM, FORCE, false>), dim3(grid), dim3(PSIM_BLOCK),
+                           t.reserve_lds, stream, s, n, p, attr_dev, na, ka);
+    return hipGetLastError();
 }
 
 template <int FORCE>
@@ -265,20 +243,39 @@ static hipError_t launch_cm(const SoaPtrs &s, uint32_t n, const psim_sim_params 
                             hipStream_t stream)
 {
     switch (p.color_mode) {
-    case 1: return launch_nt_u<1, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
-    case 2: return launch_nt_u<2, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
-    default: return launch_nt_u<0, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    case 1: return launch_nt<1, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    case 2: return launch_nt<2, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    default: return launch_nt<0, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
     }
 }
 
 uint32_t update_grid(uint32_t n, const LaunchTuning &t)
 {
     const uint32_t ngroups = n >> 2;
-    const uint32_t per_block = PSIM_BLOCK * (t.unroll >= 2 ? 2u : 1u);
-    uint32_t need = (ngroups + per_block - 1u) / per_block;
+    uint32_t need = (ngroups + PSIM_BLOCK - 1u) / PSIM_BLOCK;
     if (need == 0) need = 1;                                  // the tail still needs block 0
     if (t.max_blocks > 0 && need > t.max_blocks) need = t.max_blocks;
     return need;
+}
+
+// Launch shape by state size, from measurements on MI355X (GB/s of the 48 B/particle
+// stream; one-pass grid in every case):
+//   100 M particles: plain 5.36 k, non-temporal 5.53 k, non-temporal + at most two
+//   workgroups per CU 6.22 k (three: 5.99 k, one: 5.90 k, eight = no cap: 5.51 k);
+//   <= 12 M (state fits the 256 MiB Infinity Cache): plain 6.7-7.3 k with or without
+//   the cap (within +-3 % of each other, no consistent winner), non-temporal 5.5-6.3 k;
+//   14 M: plain and non-temporal equal; from 16 M on non-temporal + cap wins.
+// Fewer resident workgroups keep the twelve read/write streams inside a narrower
+// address window, which HBM serves better; the cap is a reservation of 64 KiB of LDS
+// per workgroup (a CU has 160 KiB).
+LaunchTuning choose_tuning(uint32_t n)
+{
+    const uint64_t state_bytes = 24ull * n;
+    LaunchTuning t;
+    t.max_blocks = 0;
+    t.nontemporal = state_bytes > 300000000ull ? 1 : 0;
+    t.reserve_lds = t.nontemporal ? 65536u : 0u;
+    return t;
 }
 
 hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &p, int force,

@@ -19,11 +19,11 @@ def main():
     ap.add_argument("--particles", type=int, default=100_000_000)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--nt", default="0,3")
-    ap.add_argument("--unroll", default="1,2")
-    ap.add_argument("--blocks", default="0,2048,4096,8192")
+    ap.add_argument("--nt", default="-1,0,1")
+    ap.add_argument("--unroll", default="1")
+    ap.add_argument("--blocks", default="-1")
     ap.add_argument("--skew", default="0")
-    ap.add_argument("--lds", default="0")
+    ap.add_argument("--lds", default="-1")
     ap.add_argument("--radius", type=float, default=10.0)
     ap.add_argument("--color", type=int, default=0)
     args = ap.parse_args()
@@ -35,9 +35,9 @@ def main():
                                       args.lds.split(",")))
     sims = {}
     for v in variants:
-        os.environ["PSIM_NT"], os.environ["PSIM_UNROLL"] = v[0], v[1]
+        os.environ["PSIM_NT"] = v[0]
         os.environ["PSIM_MAX_BLOCKS"], os.environ["PSIM_SKEW_BYTES"] = v[2], v[3]
-        os.environ["PSIM_DYN_LDS"] = v[4]
+        os.environ["PSIM_RESERVE_LDS"] = v[4]
         sims[v] = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
         for _ in range(3):
             sims[v].update(params)
