@@ -78,9 +78,9 @@ TuningOverrides read_overrides()
     return o;
 }
 
-psim::LaunchTuning tuning_for(uint32_t n, const TuningOverrides &o)
+psim::LaunchTuning tuning_for(uint32_t n, uint32_t n_attractors, const TuningOverrides &o)
 {
-    psim::LaunchTuning t = psim::choose_tuning(n);
+    psim::LaunchTuning t = psim::choose_tuning(n, n_attractors);
     if (o.nontemporal >= 0) t.nontemporal = o.nontemporal ? 1 : 0;
     if (o.reserve_lds >= 0) t.reserve_lds = (uint32_t)o.reserve_lds;
     if (o.max_blocks >= 0) t.max_blocks = (uint32_t)o.max_blocks;
@@ -405,7 +405,7 @@ PSIM_API int psim_update(psim_handle *h, const psim_sim_params *params)
     if (!params) return fail(PSIM_ERR_INVALID, "null params");
     const int force = params->is_mouse_dragging > 0 ? 1 : 0;
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, nullptr, 0,
-                                tuning_for(h->count, h->overrides),
+                                tuning_for(h->count, 1, h->overrides),
                                 h->stream));
     return PSIM_OK;
 }
@@ -423,7 +423,8 @@ PSIM_API int psim_update_multi(psim_handle *h, const psim_sim_params *params,
         return fail(PSIM_ERR_INVALID, "attractor list must be 4-byte aligned");
     const int force = n_attractors ? 2 : 0;
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, attractors_device, nullptr,
-                                n_attractors, tuning_for(h->count, h->overrides), h->stream));
+                                n_attractors, tuning_for(h->count, n_attractors, h->overrides),
+                                h->stream));
     return PSIM_OK;
 }
 
@@ -438,7 +439,8 @@ PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *param
     if (n_attractors && !attractors_host) return fail(PSIM_ERR_INVALID, "null attractor list");
     const int force = n_attractors ? 3 : 0;
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, attractors_host,
-                                n_attractors, tuning_for(h->count, h->overrides), h->stream));
+                                n_attractors, tuning_for(h->count, n_attractors, h->overrides),
+                                h->stream));
     return PSIM_OK;
 }
 
@@ -457,7 +459,7 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
     const bool vec = aligned16(px) && aligned16(py) && aligned16(pz) && aligned16(vx) &&
                      aligned16(vy) && aligned16(vz) && (!colours || aligned16(color));
     if (vec) {
-        const psim::LaunchTuning t = tuning_for(count, read_overrides());
+        const psim::LaunchTuning t = tuning_for(count, 1, read_overrides());
         HIP_TRY(psim::launch_update(s, count, *params, params->is_mouse_dragging > 0 ? 1 : 0,
                                     nullptr, nullptr, 0, t, stream));
     } else {

@@ -30,8 +30,8 @@ struct LaunchTuning {
 
 uint32_t update_grid(uint32_t n, const LaunchTuning &t);
 
-// The measured-best launch shape for a state of n particles.
-LaunchTuning choose_tuning(uint32_t n);
+// The measured-best launch shape for n particles and an attractor list of the given length.
+LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors);
 
 // force: 0 none, 1 the SimParams attractor, 2 list in device memory (staged in
 // LDS), 3 list copied from host memory into the kernel arguments.

@@ -41,10 +41,6 @@ __device__ __forceinline__ void st(T *p, T v)
 
 // ---- the per-particle step (src/simulation/cpu.rs:66-112) -------------------
 
-struct Vec3 {
-    float x, y, z;
-};
-
 // glam Vec3::length: sqrt((x*x + y*y) + z*z).
 __device__ __forceinline__ float length3(float x, float y, float z)
 {
@@ -73,29 +69,48 @@ __device__ __forceinline__ void attract(float &vx, float &vy, float &vz, float p
 
 // FORCE: 0 = no attractor, 1 = the single attractor of SimParams,
 //        2 = attractor list in LDS, 3 = attractor list in kernel arguments.
-template <int FORCE>
-__device__ __forceinline__ void step(float &px, float &py, float &pz, float &vx, float &vy,
-                                     float &vz, const psim_sim_params &p,
-                                     const psim_attractor *alist, uint32_t na)
+//
+// Steps N particles held in registers.  Particles are independent, so for a list the
+// attractor loop is the OUTER loop: each attractor record is fetched once per N
+// particles and the N divide/sqrt dependency chains interleave.  Per particle the
+// attractors are still applied in index order, which is all the arithmetic depends on.
+template <int FORCE, int N>
+__device__ __forceinline__ void step(float (&px)[N], float (&py)[N], float (&pz)[N],
+                                     float (&vx)[N], float (&vy)[N], float (&vz)[N],
+                                     const psim_sim_params &p, const psim_attractor *alist,
+                                     uint32_t na)
 {
     const float dt = p.delta_time;
-    vy = vy - p.gravity * dt;                                // cpu.rs:72
+    const float gdt = p.gravity * dt;
+#pragma unroll
+    for (int j = 0; j < N; ++j) vy[j] = vy[j] - gdt;         // cpu.rs:72
     if constexpr (FORCE == 1) {
-        attract(vx, vy, vz, px, py, pz, p.mouse_position[0], p.mouse_position[1],
-                p.mouse_position[2], p.mouse_force, p.mouse_radius * 2.0f, dt);
+        const float two_r = p.mouse_radius * 2.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            attract(vx[j], vy[j], vz[j], px[j], py[j], pz[j], p.mouse_position[0],
+                    p.mouse_position[1], p.mouse_position[2], p.mouse_force, two_r, dt);
     } else if constexpr (FORCE >= 2) {
         for (uint32_t a = 0; a < na; ++a) {
-            if (alist[a].active > 0)
-                attract(vx, vy, vz, px, py, pz, alist[a].position[0], alist[a].position[1],
-                        alist[a].position[2], alist[a].force, alist[a].radius * 2.0f, dt);
+            const psim_attractor at = alist[a];
+            if (at.active > 0) {
+                const float two_r = at.radius * 2.0f;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    attract(vx[j], vy[j], vz[j], px[j], py[j], pz[j], at.position[0],
+                            at.position[1], at.position[2], at.force, two_r, dt);
+            }
         }
     }
-    px = px + vx * dt;                                       // cpu.rs:87
-    py = py + vy * dt;
-    pz = pz + vz * dt;
-    vx = vx * p.damping;                                     // cpu.rs:90
-    vy = vy * p.damping;
-    vz = vz * p.damping;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        px[j] = px[j] + vx[j] * dt;                          // cpu.rs:87
+        py[j] = py[j] + vy[j] * dt;
+        pz[j] = pz[j] + vz[j] * dt;
+        vx[j] = vx[j] * p.damping;                           // cpu.rs:90
+        vy[j] = vy[j] * p.damping;
+        vz[j] = vz[j] * p.damping;
+    }
 }
 
 // Colour of one particle for modes 1 and 2 (cpu.rs:93-105), from the damped
@@ -170,12 +185,17 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t 
     for (uint32_t g = blockIdx.x * PSIM_BLOCK + threadIdx.x; g < ngroups; g += stride) {
         f32x4 x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
         f32x4 u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
+        float a[4], b[4], c[4], d[4], e[4], f[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float a = x[j], b = y[j], c = z[j], d = u[j], e = v[j], f = w[j];
-            step<FORCE>(a, b, c, d, e, f, p, alist, na);
-            x[j] = a; y[j] = b; z[j] = c;
-            u[j] = d; v[j] = e; w[j] = f;
+            a[j] = x[j]; b[j] = y[j]; c[j] = z[j];
+            d[j] = u[j]; e[j] = v[j]; f[j] = w[j];
+        }
+        step<FORCE, 4>(a, b, c, d, e, f, p, alist, na);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
+            u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
         }
         st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
         st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
@@ -189,11 +209,12 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t 
     // Tail: particles 4*ngroups .. n-1.
     if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
         const uint32_t i = (ngroups << 2) + threadIdx.x;
-        float x = s.px[i], y = s.py[i], z = s.pz[i], u = s.vx[i], v = s.vy[i], w = s.vz[i];
-        step<FORCE>(x, y, z, u, v, w, p, alist, na);
-        s.px[i] = x; s.py[i] = y; s.pz[i] = z;
-        s.vx[i] = u; s.vy[i] = v; s.vz[i] = w;
-        if constexpr (CM != 0) col4[i] = colour<CM>(x, y, z, u, v, w, p);
+        float x[1] = {s.px[i]}, y[1] = {s.py[i]}, z[1] = {s.pz[i]};
+        float u[1] = {s.vx[i]}, v[1] = {s.vy[i]}, w[1] = {s.vz[i]};
+        step<FORCE, 1>(x, y, z, u, v, w, p, alist, na);
+        s.px[i] = x[0]; s.py[i] = y[0]; s.pz[i] = z[0];
+        s.vx[i] = u[0]; s.vy[i] = v[0]; s.vz[i] = w[0];
+        if constexpr (CM != 0) col4[i] = colour<CM>(x[0], y[0], z[0], u[0], v[0], w[0], p);
     }
 }
 
@@ -203,15 +224,16 @@ template <int CM, int FORCE>
 __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel_scalar(SoaPtrs s, uint32_t n,
                                                                   psim_sim_params p)
 {
-    const uint32_t stride = gridDim.x * PSIM_BLOCK;
-    for (uint32_t i = blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
-        float x = s.px[i], y = s.py[i], z = s.pz[i], u = s.vx[i], v = s.vy[i], w = s.vz[i];
-        step<FORCE>(x, y, z, u, v, w, p, nullptr, 0);
-        s.px[i] = x; s.py[i] = y; s.pz[i] = z;
-        s.vx[i] = u; s.vy[i] = v; s.vz[i] = w;
+    const uint64_t stride = (uint64_t)gridDim.x * PSIM_BLOCK;    // 64-bit: i + stride may pass 2^32
+    for (uint64_t i = (uint64_t)blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
+        float x[1] = {s.px[i]}, y[1] = {s.py[i]}, z[1] = {s.pz[i]};
+        float u[1] = {s.vx[i]}, v[1] = {s.vy[i]}, w[1] = {s.vz[i]};
+        step<FORCE, 1>(x, y, z, u, v, w, p, nullptr, 0);
+        s.px[i] = x[0]; s.py[i] = y[0]; s.pz[i] = z[0];
+        s.vx[i] = u[0]; s.vy[i] = v[0]; s.vz[i] = w[0];
         if constexpr (CM != 0) {
-            const f32x4 c = colour<CM>(x, y, z, u, v, w, p);
-            float *dst = s.color + 4ull * i;                 // may be only 4-byte aligned
+            const f32x4 c = colour<CM>(x[0], y[0], z[0], u[0], v[0], w[0], p);
+            float *dst = s.color + 4 * i;                    // may be only 4-byte aligned
             dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3];
         }
     }
@@ -268,13 +290,18 @@ uint32_t update_grid(uint32_t n, const LaunchTuning &t)
 // Fewer resident workgroups keep the twelve read/write streams inside a narrower
 // address window, which HBM serves better; the cap is a reservation of 64 KiB of LDS
 // per workgroup (a CU has 160 KiB).
-LaunchTuning choose_tuning(uint32_t n)
+//
+// Attractor lists add ~80 VALU instructions per particle and attractor, in long
+// divide/sqrt dependency chains; two workgroups per CU (two waves per SIMD) cannot hide
+// them.  At 100 M particles, ms per step with / without the cap: 1-2 attractors
+// 0.74-0.76 / 0.87-0.88, 4 attractors 0.88 / 0.87, 8 attractors 1.47 / 0.96.
+LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
 {
     const uint64_t state_bytes = 24ull * n;
     LaunchTuning t;
     t.max_blocks = 0;
     t.nontemporal = state_bytes > 300000000ull ? 1 : 0;
-    t.reserve_lds = t.nontemporal ? 65536u : 0u;
+    t.reserve_lds = (t.nontemporal && n_attractors < 4) ? 65536u : 0u;
     return t;
 }
 
@@ -351,8 +378,8 @@ __global__ void __launch_bounds__(PSIM_BLOCK) gen_uniform_kernel(SoaPtrs s, uint
                                                                 uint64_t global_first,
                                                                 uint64_t seed)
 {
-    const uint32_t stride = gridDim.x * PSIM_BLOCK;
-    for (uint32_t i = blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * PSIM_BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
         const uint64_t c0 = 6ull * (global_first + i);
         float pos[3], vel[3];
 #pragma unroll
@@ -480,8 +507,8 @@ __global__ void __launch_bounds__(PSIM_BLOCK) checksum_kernel(SoaPtrs s, uint32_
 {
     const float *arr[6] = {s.px, s.py, s.pz, s.vx, s.vy, s.vz};
     uint64_t acc[6] = {0, 0, 0, 0, 0, 0};
-    const uint32_t stride = gridDim.x * PSIM_BLOCK;
-    for (uint32_t i = blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * PSIM_BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[k] += __float_as_uint(arr[k][i]);
     }

@@ -116,6 +116,28 @@ def test_hundred_million_particles_checksum_and_slices():
     assert gpu_sum == want_sum
 
 
+def test_more_than_two_to_the_31_particles():
+    """Maximum-size edge: 2.2 G particles (141 GB of the 288 GB HBM) in one handle, past
+    every 31-bit index.  Slices at the start, across 2^31 and at the end must match the
+    oracle; a wrapped grid-stride index would step low particles twice."""
+    n = 2_200_000_003
+    params = T.bench_params(mouse_radius=50.0, gravity=1.0)
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        assert sim.get_particle_count() == n
+        before = sim.checksum()
+        for _ in range(2):
+            sim.update(params)
+        slices = [(0, 3000), (2**31 - 1500, 3000), (n - 3003, 3003)]
+        got = [sim.download_soa(f, m) for f, m in slices]
+        aos = sim.download_aos(2**31 - 64, 128)
+        assert sim.checksum() != before
+    for (f, m), g in zip(slices, got):
+        want, _ = T.oracle_update_soa(T.oracle_gen_uniform_soa(f, m), params, 2)
+        T.assert_same_f32(g, want, f"slice [{f}, +{m})")
+    want = T.oracle_update_aos(T.oracle_gen_uniform_aos(2**31 - 64, 128), params, 2)
+    T.assert_particles_equal(aos, want, "AoS export across 2^31")
+
+
 # ---- multi-attractor extension ----------------------------------------------------------
 
 def _attractors(rng, k):
