@@ -89,6 +89,11 @@ def load_traffic(particles):
 
 def main():
     args = parse_args()
+    # Native libraries (RCCL's start-up banner) write to file descriptor 1; keep it for the
+    # single JSON line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch                       # first: the C-ABI library then shares torch's HIP runtime
     import torch.distributed as dist
 
@@ -101,7 +106,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this benchmark has no CPU path")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1 or args.workload == "multi"
+    # under torch.distributed.run (RANK set) the process group is used even for one rank
+    distributed = world > 1 or args.workload == "multi" or "RANK" in os.environ
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -194,7 +200,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     sim.close()
     if distributed:

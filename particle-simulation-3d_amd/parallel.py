@@ -122,25 +122,26 @@ class MultiAttractorRunner:
         self.recv = [torch.zeros(world * ATTRACTOR_FLOATS, dtype=torch.float32, device=dev)
                      for _ in range(2)]
         self.gathered = [torch.cuda.Event() for _ in range(2)]
-        self.kernel_done = [None, None]
+        self.kernel_done = [torch.cuda.Event() for _ in range(2)]
+        self.send_ptr = [t.data_ptr() for t in self.send]
+        self.recv_ptr = [t.data_ptr() for t in self.recv]
+        self.comm_ptr = self.comm.cuda_stream
         self.t = 0
 
     def step(self):
         torch, dist = self._torch, self._dist
         b = self.t % 2
         with torch.cuda.stream(self.comm):
-            if self.kernel_done[b] is not None:
+            if self.t >= 2:                    # the kernel of step t-2 read recv[b]
                 self.comm.wait_event(self.kernel_done[b])
-            store_attractor(self.send[b].data_ptr(),
+            store_attractor(self.send_ptr[b],
                             attractor_at(self.t, self.rank, self.force, self.radius),
-                            self.comm.cuda_stream)
+                            self.comm_ptr)
             dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self._group)
             self.gathered[b].record(self.comm)
         self.compute.wait_event(self.gathered[b])
-        self.sim.update_multi_device(self.params, self.recv[b].data_ptr(), self.world)
-        ev = torch.cuda.Event()
-        ev.record(self.compute)
-        self.kernel_done[b] = ev
+        self.sim.update_multi_device(self.params, self.recv_ptr[b], self.world)
+        self.kernel_done[b].record(self.compute)
         self.t += 1
 
     def finish(self):
