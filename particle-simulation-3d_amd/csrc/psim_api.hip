@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "psim_kernels.h"
@@ -267,8 +268,26 @@ int generate(psim_handle *h, int mode)
         for (uint64_t k = 0; k < 3 * gfirst; ++k) rng.next();   // skip earlier shards' draws
     for (uint64_t done = 0; done < h->count; done += chunk) {
         const uint64_t m = (h->count - done) < chunk ? (h->count - done) : chunk;
-        if (mode == PSIM_GEN_HOLLOW) gen_hollow(host.data(), gcount32, gfirst + done, m);
-        else gen_filled(host.data(), rng, m);
+        if (mode == PSIM_GEN_HOLLOW) {
+            // index-addressed: split the chunk over a few host threads
+            const unsigned hw = std::thread::hardware_concurrency();
+            const uint64_t workers = m < 65536 ? 1 : (hw == 0 ? 4 : (hw > 16 ? 16 : hw));
+            const uint64_t per = (m + workers - 1) / workers;
+            std::vector<std::thread> pool;
+            for (uint64_t w = 1; w < workers && w * per < m; ++w) {
+                const uint64_t lo = w * per, len = (m - lo) < per ? (m - lo) : per;
+                try {
+                    pool.emplace_back(gen_hollow, host.data() + lo, gcount32, gfirst + done + lo,
+                                      len);
+                } catch (...) {                                  // no thread: do it here
+                    gen_hollow(host.data() + lo, gcount32, gfirst + done + lo, len);
+                }
+            }
+            gen_hollow(host.data(), gcount32, gfirst + done, per < m ? per : m);
+            for (auto &t : pool) t.join();
+        } else {
+            gen_filled(host.data(), rng, m);                    // one sequential random stream
+        }
         int rc = upload_aos_chunked(h, host.data(), done, m);
         if (rc != PSIM_OK) return rc;
     }

@@ -256,6 +256,22 @@ def build_cases():
     one["active"] = 1
     cases["multi1_equals_single"] = (batch.copy(),
                                      make_params(is_mouse_dragging=1, mouse_position=att), one)
+    # numeric extremes: subnormal state (no flush to zero anywhere: sqrt, divide and the
+    # compare must all work on subnormals), and magnitudes whose squares overflow
+    tiny = particles_from(rng.uniform(-1, 1, size=(64, 3)) * 1e-39,
+                          rng.uniform(-1, 1, size=(64, 3)) * 1e-40)
+    cases["subnormal_state"] = (tiny, make_params(is_mouse_dragging=1, mouse_radius=1e-38,
+                                                  mouse_force=5.0, gravity=1e-38,
+                                                  mouse_position=(0.0, 0.0, 0.0)), None)
+    cases["subnormal_color2"] = (tiny.copy(), make_params(color_mode=2, max_dist_for_color=50.0,
+                                                          is_mouse_dragging=0), None)
+    huge = particles_from(rng.uniform(-1, 1, size=(64, 3)) * 1e30,
+                          rng.uniform(-1, 1, size=(64, 3)) * 1e25)
+    huge["position"][:8] = rng.uniform(-1, 1, size=(8, 3)) * 1e18       # squares still finite
+    cases["huge_magnitudes"] = (huge, make_params(is_mouse_dragging=1, mouse_radius=1e20,
+                                                  mouse_force=100.0, color_mode=1,
+                                                  mouse_position=att), None)
+    cases["huge_color2"] = (huge.copy(), make_params(color_mode=2, is_mouse_dragging=0), None)
     return cases
 
 

@@ -238,3 +238,15 @@ def test_checksum_oracle_is_sum_of_bit_patterns():
     soa = T.oracle_gen_uniform_soa(0, 1000)
     want = [int(soa[k].view(np.uint32).astype(np.uint64).sum()) for k in range(6)]
     assert T.oracle_checksum_soa(soa) == want
+
+
+def test_oracle_runs_clean_under_sanitizers():
+    """AddressSanitizer + UBSan over every oracle entry point (host code only)."""
+    import os
+    import subprocess
+    subprocess.check_call(["make", "-C", T.ORACLE_DIR, "selftest"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    r = subprocess.run([os.path.join(T.ORACLE_DIR, "selftest")], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "oracle selftest OK" in r.stdout
