@@ -19,7 +19,8 @@ from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_uint32, c_uint64,
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "csrc", "libpsim_hip.so")
+# PSIM_LIBRARY selects another build of the same library (kernel experiments).
+LIBRARY_PATH = os.environ.get("PSIM_LIBRARY") or os.path.join(_HERE, "csrc", "libpsim_hip.so")
 
 # ---- records shared with the reference ---------------------------------------
 

@@ -8,7 +8,12 @@
 
 #include "../../include/psim.h"
 
-#define PSIM_BLOCK 256               /* threads per workgroup = 4 wave64 */
+#ifndef PSIM_BLOCK
+#define PSIM_BLOCK 256               /* threads per workgroup = 4 wave64 (all but the update) */
+#endif
+#ifndef PSIM_UPDATE_BLOCK
+#define PSIM_UPDATE_BLOCK 64         /* the update kernel: single-wave workgroups */
+#endif
 #define PSIM_KERNARG_ATTRACTORS 8u   /* attractor list size that fits the kernel arguments */
 
 namespace psim {

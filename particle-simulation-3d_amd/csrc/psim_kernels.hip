@@ -142,30 +142,38 @@ struct KernargAttractors {
 //
 // CM    colour mode 0 (colour untouched, 48 B/particle), 1 or 2 (+16 B store).
 // FORCE see step().
-// NT    non-temporal loads and stores of the six state arrays: a state larger
-//       than the 256 MiB Infinity Cache is streamed once per step, so keeping its
-//       lines cached only evicts useful ones (+3..4 % at 100 M particles); a
-//       cache-resident state (<= ~12 M particles) is faster with plain accesses.
-//       Colour stores are always plain: a lane writes 4 x 16 B at a 64 B stride
-//       per instruction, and only plain stores are merged into whole lines in L2
-//       (non-temporal colour stores ran 2.4x slower).
+// NT    non-temporal loads and stores: a state larger than the 256 MiB Infinity
+//       Cache is streamed once per step, so keeping its lines cached only evicts
+//       useful ones; a cache-resident state is faster with plain accesses.
 //
-// Grid-stride over groups of 4 consecutive particles; a launch whose grid covers
-// every group runs the loop once (the fastest shape measured: workgroups are
-// dispatched in index order, so the resident ones sweep a narrow window of each
-// array).  The last n % 4 particles are stepped one at a time by workgroup 0.
+// A lane owns a group of 4 consecutive particles: one 16-byte access per array, so each
+// wave instruction covers 1 KiB of consecutive addresses.  Grid-stride over groups; a
+// launch whose grid covers every group runs the loop once (the fastest shape measured:
+// workgroups are dispatched in index order, so the resident ones sweep a narrow window
+// of each array).  The last n % 4 particles are stepped one at a time by workgroup 0.
+//
+// Colour (modes 1/2): a lane's 4 RGBA values are 64 consecutive bytes, so storing them
+// straight from the lane would write 16 B at a 64 B stride per instruction (measured:
+// 2.4x slower with non-temporal stores, 15 % slower with plain ones).  Instead the wave
+// transposes them through LDS and stores 1 KiB of consecutive bytes per instruction.
+// LDS image per wave: [j][lane] with rows of 68 quads; the 4 writes are lane-linear and
+// the reads (lane L, instruction k -> quad [L%4][16k + L/4]) touch 16 distinct 16-byte
+// bank slots per 16-lane group, so neither side has a bank conflict.
+#define PSIM_COLOUR_ROW 68   /* quads per LDS row: 64 + 4 of padding */
+
 template <int CM, int FORCE, bool NT>
-__global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t n,
-                                                           psim_sim_params p,
-                                                           const psim_attractor *attr_dev,
-                                                           uint32_t na, KernargAttractors ka)
+__global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, uint32_t n,
+                                                                  psim_sim_params p,
+                                                                  const psim_attractor *attr_dev,
+                                                                  uint32_t na,
+                                                                  KernargAttractors ka)
 {
     const psim_attractor *alist = nullptr;
     if constexpr (FORCE == 2) {
         // Stage the attractor list (<= 2 KiB) into LDS once per workgroup.
         __shared__ psim_attractor lds_attr[PSIM_MAX_ATTRACTORS];
         const uint32_t words = na * (sizeof(psim_attractor) / 4u);
-        for (uint32_t w = threadIdx.x; w < words; w += PSIM_BLOCK)
+        for (uint32_t w = threadIdx.x; w < words; w += PSIM_UPDATE_BLOCK)
             reinterpret_cast<uint32_t *>(lds_attr)[w] =
                 reinterpret_cast<const uint32_t *>(attr_dev)[w];
         __syncthreads();
@@ -180,29 +188,58 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel(SoaPtrs s, uint32_t 
     f32x4 *col4 = reinterpret_cast<f32x4 *>(s.color);
 
     const uint32_t ngroups = n >> 2;
-    const uint32_t stride = gridDim.x * PSIM_BLOCK;          // groups per grid pass
-    // Each wave instruction covers 1 KiB of consecutive addresses of one array.
-    for (uint32_t g = blockIdx.x * PSIM_BLOCK + threadIdx.x; g < ngroups; g += stride) {
-        f32x4 x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
-        f32x4 u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
-        float a[4], b[4], c[4], d[4], e[4], f[4];
+    const uint32_t stride = gridDim.x * PSIM_UPDATE_BLOCK;   // groups per grid pass
+    const uint32_t lane = threadIdx.x & 63u;
+    // The trip count is the same for every lane of a wave (the colour transposition
+    // needs the whole wave); lanes past the end are masked by `live`.
+    for (uint32_t g0 = blockIdx.x * PSIM_UPDATE_BLOCK + (threadIdx.x & ~63u); g0 < ngroups;
+         g0 += stride) {
+        const uint32_t g = g0 + lane;
+        const bool live = g < ngroups;
+        f32x4 col[4];
+        if (live) {
+            f32x4 x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
+            f32x4 u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
+            float a[4], b[4], c[4], d[4], e[4], f[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[j] = x[j]; b[j] = y[j]; c[j] = z[j];
-            d[j] = u[j]; e[j] = v[j]; f[j] = w[j];
-        }
-        step<FORCE, 4>(a, b, c, d, e, f, p, alist, na);
+            for (int j = 0; j < 4; ++j) {
+                a[j] = x[j]; b[j] = y[j]; c[j] = z[j];
+                d[j] = u[j]; e[j] = v[j]; f[j] = w[j];
+            }
+            step<FORCE, 4>(a, b, c, d, e, f, p, alist, na);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
-            u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
+            for (int j = 0; j < 4; ++j) {
+                x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
+                u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
+            }
+            st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
+            st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
+            if constexpr (CM != 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    col[j] = colour<CM>(a[j], b[j], c[j], d[j], e[j], f[j], p);
+            }
         }
-        st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
-        st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
         if constexpr (CM != 0) {
+            __shared__ f32x4 tile[PSIM_UPDATE_BLOCK / 64][4][PSIM_COLOUR_ROW];
+            f32x4(*t)[PSIM_COLOUR_ROW] = tile[threadIdx.x >> 6];
+            if (live) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                col4[4ull * g + j] = colour<CM>(x[j], y[j], z[j], u[j], v[j], w[j], p);
+                for (int j = 0; j < 4; ++j) t[j][lane] = col[j];
+            }
+            // LDS operations of one wave execute in order; the fences only pin the
+            // compiler's ordering of the writes above against the reads below.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t q = k * 64u + lane;                // quad within the wave's 4 KiB
+                const uint32_t src = q >> 2;                      // lane that computed it
+                if (g0 + src < ngroups) st<NT>(col4 + 4ull * g0 + q, t[q & 3u][src]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                      // next trip rewrites the tile
         }
     }
 
@@ -249,12 +286,16 @@ static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params 
 {
     // t.reserve_lds bytes of dynamic LDS are requested but never touched: they only
     // limit how many workgroups a CU holds at once (see choose_tuning()).
+    // The reservation counts the LDS the kernel itself declares.
+    constexpr uint32_t used = (CM != 0 ? (PSIM_UPDATE_BLOCK / 64) * 4 * PSIM_COLOUR_ROW * 16 : 0) +
+                              (FORCE == 2 ? PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) : 0);
+    const uint32_t extra = t.reserve_lds > used ? t.reserve_lds - used : 0;
     if (t.nontemporal)
-        hipLaunchKernelGGL((update_kernel<CM, FORCE, true>), dim3(grid), dim3(PSIM_BLOCK),
-                           t.reserve_lds, stream, s, n, p, attr_dev, na, ka);
+        hipLaunchKernelGGL((update_kernel<CM, FORCE, true>), dim3(grid), dim3(PSIM_UPDATE_BLOCK),
+                           extra, stream, s, n, p, attr_dev, na, ka);
     else
-        hipLaunchKernelGGL((update_kernel<CM, FORCE, false>), dim3(grid), dim3(PSIM_BLOCK),
-                           t.reserve_lds, stream, s, n, p, attr_dev, na, ka);
+        hipLaunchKernelGGL((update_kernel<CM, FORCE, false>), dim3(grid), dim3(PSIM_UPDATE_BLOCK),
+                           extra, stream, s, n, p, attr_dev, na, ka);
     return hipGetLastError();
 }
 
@@ -274,34 +315,38 @@ static hipError_t launch_cm(const SoaPtrs &s, uint32_t n, const psim_sim_params 
 uint32_t update_grid(uint32_t n, const LaunchTuning &t)
 {
     const uint32_t ngroups = n >> 2;
-    uint32_t need = (ngroups + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    uint32_t need = (ngroups + PSIM_UPDATE_BLOCK - 1u) / PSIM_UPDATE_BLOCK;
     if (need == 0) need = 1;                                  // the tail still needs block 0
     if (t.max_blocks > 0 && need > t.max_blocks) need = t.max_blocks;
     return need;
 }
 
-// Launch shape by state size, from measurements on MI355X (GB/s of the 48 B/particle
-// stream; one-pass grid in every case):
-//   100 M particles: plain 5.36 k, non-temporal 5.53 k, non-temporal + at most two
-//   workgroups per CU 6.22 k (three: 5.99 k, one: 5.90 k, eight = no cap: 5.51 k);
-//   <= 12 M (state fits the 256 MiB Infinity Cache): plain 6.7-7.3 k with or without
-//   the cap (within +-3 % of each other, no consistent winner), non-temporal 5.5-6.3 k;
-//   14 M: plain and non-temporal equal; from 16 M on non-temporal + cap wins.
-// Fewer resident workgroups keep the twelve read/write streams inside a narrower
-// address window, which HBM serves better; the cap is a reservation of 64 KiB of LDS
-// per workgroup (a CU has 160 KiB).
+// Launch shape, from measurements on MI355X (GB/s of the 48 B/particle stream, 100 M
+// particles unless noted).  Grid: one pass over the array beats a capped grid-stride grid
+// (2048-8192 workgroups: 4.3-4.9 k).  Accesses: plain 5.36 k, non-temporal 5.53 k.
+// Resident waves per CU, non-temporal, by workgroup size and LDS reservation:
+//   256 threads: 32 waves (no cap) 5.5 k | 12 waves 5.99 k | 8 waves 6.22 k | 4 waves 5.90 k
+//   128 threads: 10 waves 6.26 k | 6 waves 6.23-6.30 k | 4 waves 5.34 k
+//    64 threads: 10 waves 6.35 k | 7 waves 6.39 k | 6 waves 6.34 k | 5 waves 5.35 k
+// Fewer resident waves keep the twelve read/write streams inside a narrower address
+// window, which HBM serves better, until too few bytes are in flight; single-wave
+// workgroups give the finest control, so the update kernel runs 64-thread workgroups and
+// reserves (never touches) 23040 B of LDS per workgroup: 7 of them fit a CU's 160 KiB.
+// By size (64 threads): 1 M particles plain without cap 7.3 k (cap 6.2 k); 6.25-14 M plain
+// + cap 6.6-7.0 k (the state fits the 256 MiB Infinity Cache); from 20 M on
+// non-temporal + cap 6.4 k (plain + cap 5.9 k).
 //
 // Attractor lists add ~80 VALU instructions per particle and attractor, in long
-// divide/sqrt dependency chains; two workgroups per CU (two waves per SIMD) cannot hide
-// them.  At 100 M particles, ms per step with / without the cap: 1-2 attractors
-// 0.74-0.76 / 0.87-0.88, 4 attractors 0.88 / 0.87, 8 attractors 1.47 / 0.96.
+// divide/sqrt dependency chains that a few waves per SIMD cannot hide.  At 100 M
+// particles (256-thread workgroups), ms per step with / without an 8-wave cap:
+// 1-2 attractors 0.74-0.76 / 0.87-0.88, 4 attractors 0.88 / 0.87, 8 attractors 1.47 / 0.96.
 LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
 {
     const uint64_t state_bytes = 24ull * n;
     LaunchTuning t;
     t.max_blocks = 0;
-    t.nontemporal = state_bytes > 300000000ull ? 1 : 0;
-    t.reserve_lds = (t.nontemporal && n_attractors < 4) ? 65536u : 0u;
+    t.nontemporal = state_bytes > 400000000ull ? 1 : 0;
+    t.reserve_lds = (state_bytes >= 96000000ull && n_attractors < 4) ? 23040u : 0u;
     return t;
 }
 
