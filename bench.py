@@ -2,13 +2,17 @@
 """Benchmark of the particle-update hot path on MI355X.
 
 A step is one update (one kernel launch) of this rank's particle shard.  At N = 1 the
-workload is BASELINE.json's headline configuration: 100 M particles, single attractor,
-fp32, synthetic uniform-random state generated on the device.  With N > 1 every rank
-holds its own 100 M-particle shard of an N x 100 M array (weak scaling); the
-single-attractor path needs no communication, so torch.distributed is used only for
-the barriers and the max-over-ranks of the timing.
+workload is the headline configuration: 100 M particles, single attractor, fp32,
+synthetic uniform-random state generated on the device.  With N > 1 every rank holds its
+own 100 M-particle shard of an N x 100 M array (weak scaling); the single-attractor path
+needs no communication, so torch.distributed is used only for the barriers and the
+max-over-ranks of the timing.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+Prints ONE JSON line on rank 0: whole-job particle-updates/s over the timed steps, plus
+`roofline` (algorithmic bytes per launch / HIP-event launch duration against the HBM peak,
+and the HBM traffic measured with rocprofv3 counters when a summary for this size is
+present under profiles/) and, at N = 1, `cpu_baseline` (the CPU restatement of the
+reference's update timed on the host cores).
 """
 from __future__ import annotations
 

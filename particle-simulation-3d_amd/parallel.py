@@ -35,13 +35,20 @@ def attractor_at(step, index, force=5.0, radius=10.0):
     """Attractor `index` at step `step`: a closed-form Lissajous path inside the
     50-unit world cube (evaluated in float64, rounded once to fp32), so every rank and
     the CPU oracle can reproduce any attractor at any step without communication."""
-    t = 0.01 * step
-    a = np.zeros(1, dtype=ATTRACTOR_DTYPE)
-    a["position"][0] = (
-        40.0 * math.sin((1.0 + 0.25 * index) * t + 0.7 * index),
-        40.0 * math.sin((1.5 + 0.125 * index) * t + 1.3 * index),
-        40.0 * math.cos((0.75 + 0.0625 * index) * t + 0.4 * index),
-    )
+    return attractor_table(step, 1, index, force, radius)
+
+
+def attractor_table(first_step, count, index, force=5.0, radius=10.0):
+    """Attractor `index` at steps first_step .. first_step + count - 1 (one record each)."""
+    a = np.zeros(count, dtype=ATTRACTOR_DTYPE)
+    pos = a["position"]
+    wx, wy, wz = 1.0 + 0.25 * index, 1.5 + 0.125 * index, 0.75 + 0.0625 * index
+    px, py, pz = 0.7 * index, 1.3 * index, 0.4 * index
+    for k in range(count):
+        t = 0.01 * (first_step + k)
+        pos[k, 0] = 40.0 * math.sin(wx * t + px)
+        pos[k, 1] = 40.0 * math.sin(wy * t + py)
+        pos[k, 2] = 40.0 * math.cos(wz * t + pz)
     a["force"] = force
     a["radius"] = radius
     a["active"] = 1
@@ -127,22 +134,37 @@ class MultiAttractorRunner:
         self.recv_ptr = [t.data_ptr() for t in self.recv]
         self.comm_ptr = self.comm.cuda_stream
         self.t = 0
+        # The collective is ordered on torch's CURRENT stream, so the communication stream
+        # is made current for the life of the runner (cheaper than entering a stream
+        # context every step; the kernels of this library take their stream explicitly).
+        self._previous_stream = torch.cuda.current_stream(dev)
+        torch.cuda.set_stream(self.comm)
+        self._path = None          # own attractor records for steps [_path_first, +len)
+        self._path_first = 0
+
+    def _own_attractor(self, t):
+        """This rank's attractor at step t, from a table refilled 256 steps at a time."""
+        if self._path is None or not self._path_first <= t < self._path_first + len(self._path):
+            self._path_first = t
+            self._path = attractor_table(t, 256, self.rank, self.force, self.radius)
+        return self._path[t - self._path_first:t - self._path_first + 1]
 
     def step(self):
-        torch, dist = self._torch, self._dist
         b = self.t % 2
-        with torch.cuda.stream(self.comm):
-            if self.t >= 2:                    # the kernel of step t-2 read recv[b]
-                self.comm.wait_event(self.kernel_done[b])
-            store_attractor(self.send_ptr[b],
-                            attractor_at(self.t, self.rank, self.force, self.radius),
-                            self.comm_ptr)
-            dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self._group)
-            self.gathered[b].record(self.comm)
+        if self.t >= 2:                        # the kernel of step t-2 read recv[b]
+            self.comm.wait_event(self.kernel_done[b])
+        store_attractor(self.send_ptr[b], self._own_attractor(self.t), self.comm_ptr)
+        self._dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self._group)
+        self.gathered[b].record(self.comm)
         self.compute.wait_event(self.gathered[b])
         self.sim.update_multi_device(self.params, self.recv_ptr[b], self.world)
         self.kernel_done[b].record(self.compute)
         self.t += 1
+
+    def close(self):
+        self.finish()
+        self._torch.cuda.set_stream(self._previous_stream)
+        self.sim.close()
 
     def finish(self):
         self.compute.synchronize()

@@ -86,5 +86,22 @@ def main():
               + ("   (host-synchronous call)" if sync_each else ""), flush=True)
 
 
+    # host transfers of the 64-byte records (device transposition + PCIe copy, synchronous)
+    import time
+    m = min(n, 10_000_000)
+    for name, fn in (("download AoS to host", lambda: sim.download_aos(0, m)),):
+        fn()
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        print(f"{name:<48} | {dt * 1e3:9.3f} | {64 * m / dt / 1e9:9.2f} | {m / dt / 1e9:12.3f}"
+              f"   ({m} particles, pageable host memory)")
+    t0 = time.perf_counter()
+    sim.upload_aos(out, 0)
+    dt = time.perf_counter() - t0
+    print(f"{'upload AoS from host':<48} | {dt * 1e3:9.3f} | {64 * m / dt / 1e9:9.2f} | "
+          f"{m / dt / 1e9:12.3f}   ({m} particles, pageable host memory)")
+
+
 if __name__ == "__main__":
     main()

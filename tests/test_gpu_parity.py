@@ -55,7 +55,7 @@ def test_golden_case(golden_update, name):
         T.assert_particles_equal(got, want, f"{name}/{steps} steps")
 
 
-# ---- BASELINE configurations against the oracle ---------------------------------------
+# ---- the benchmark configurations against the oracle ---------------------------------------
 
 @pytest.mark.parametrize("n", [100_000, 1_000_003])
 @pytest.mark.parametrize("kw", [
@@ -79,7 +79,7 @@ def test_uniform_state_matches_oracle(n, kw):
 
 
 def test_ten_million_particles_match_oracle():
-    """BASELINE config: 10 M particles, single attractor, fp32."""
+    """The 10 M-particle single-attractor configuration, value by value."""
     n = 10_000_000
     params = T.bench_params()
     with Sim.new(n, psim.GEN_UNIFORM) as sim:
@@ -93,7 +93,7 @@ def test_ten_million_particles_match_oracle():
 
 
 def test_hundred_million_particles_checksum_and_slices():
-    """BASELINE config: 100 M particles.  The whole state is compared through an
+    """The 100 M-particle headline configuration.  The whole state is compared through an
     order-independent checksum (sum of bit patterns per component) computed on the
     device and by the oracle; three slices are compared value by value."""
     n = 100_000_000
