@@ -28,7 +28,6 @@ sys.path.insert(0, ROOT)
 
 ALGORITHMIC_BYTES_PER_UPDATE = 48      # 6 fp32 read + 6 fp32 written, colour mode 0
 HBM_PEAK_GBPS = 8000.0                 # MI355X HBM3E datasheet peak
-UPDATE_KERNEL = "update_kernel<0, 1,"  # colour mode 0, single attractor
 
 
 def parse_args():

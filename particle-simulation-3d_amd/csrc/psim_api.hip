@@ -478,7 +478,8 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
     const bool vec = aligned16(px) && aligned16(py) && aligned16(pz) && aligned16(vx) &&
                      aligned16(vy) && aligned16(vz) && (!colours || aligned16(color));
     if (vec) {
-        const psim::LaunchTuning t = tuning_for(count, 1, read_overrides());
+        static const TuningOverrides overrides = read_overrides();   // read once per process
+        const psim::LaunchTuning t = tuning_for(count, 1, overrides);
         HIP_TRY(psim::launch_update(s, count, *params, params->is_mouse_dragging > 0 ? 1 : 0,
                                     nullptr, nullptr, 0, t, stream));
     } else {

@@ -461,13 +461,15 @@ hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_firs
 // A workgroup moves PSIM_BLOCK particles = 16 KiB of AoS.  The AoS side is
 // accessed as a linear run of quads (lane t touches quad k*PSIM_BLOCK + t, so a
 // wave instruction covers 1 KiB of consecutive bytes); the transposition happens
-// in LDS.  LDS holds quads at [field][particle] so both phases are conflict-free
-// 16-byte accesses.
+// in LDS.  LDS holds quads at [field][particle]; the per-particle side is lane-linear,
+// and the rows are padded so that the AoS-order side (lane t -> [t & 3][k*64 + t/4]) is
+// free of bank conflicts too: by 4 quads for the 16-byte reads of the export (banks
+// taken modulo 64 dwords), by 2 quads for the 16-byte writes of the import (modulo 32).
 
 __global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint32_t first,
                                                                uint32_t n, f32x4 *aos)
 {
-    __shared__ f32x4 tile[4][PSIM_BLOCK];
+    __shared__ f32x4 tile[4][PSIM_BLOCK + 4];
     const uint32_t base = blockIdx.x * PSIM_BLOCK;            // first particle of the tile
     const uint32_t t = threadIdx.x;
     const uint32_t i = base + t;
@@ -492,7 +494,7 @@ __global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint3
 __global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint32_t first,
                                                                uint32_t n, const f32x4 *aos)
 {
-    __shared__ f32x4 tile[4][PSIM_BLOCK];
+    __shared__ f32x4 tile[4][PSIM_BLOCK + 2];
     const uint32_t base = blockIdx.x * PSIM_BLOCK;
     const uint32_t t = threadIdx.x;
     const uint32_t live = (n - base) < PSIM_BLOCK ? (n - base) : PSIM_BLOCK;
@@ -552,8 +554,19 @@ __global__ void __launch_bounds__(PSIM_BLOCK) checksum_kernel(SoaPtrs s, uint32_
 {
     const float *arr[6] = {s.px, s.py, s.pz, s.vx, s.vy, s.vz};
     uint64_t acc[6] = {0, 0, 0, 0, 0, 0};
+    // 16-byte loads over groups of 4 particles, then the n % 4 tail one by one
+    const uint32_t ngroups = n >> 2;
     const uint64_t stride = (uint64_t)gridDim.x * PSIM_BLOCK;
-    for (uint64_t i = (uint64_t)blockIdx.x * PSIM_BLOCK + threadIdx.x; i < n; i += stride) {
+    for (uint64_t g = (uint64_t)blockIdx.x * PSIM_BLOCK + threadIdx.x; g < ngroups; g += stride) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const f32x4 q = reinterpret_cast<const f32x4 *>(arr[k])[g];
+            acc[k] += (uint64_t)__float_as_uint(q[0]) + __float_as_uint(q[1]) +
+                      __float_as_uint(q[2]) + __float_as_uint(q[3]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
+        const uint32_t i = (ngroups << 2) + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[k] += __float_as_uint(arr[k][i]);
     }
