@@ -30,6 +30,25 @@ def test_oracle_equals_numpy_restatement_on_random_cases():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dragging", [0, 1])
+def test_long_run_stays_bit_identical(dragging):
+    """12 000 steps: with damping 0.99 the velocities decay through the subnormal range
+    (0.99^12000 ~ 4e-53) until rounding pins them at a few dozen units of 2^-149, so every
+    step of the decay must round like the oracle; with the attractor held, particles near
+    it keep moving instead."""
+    n, steps = 100_000, 12_000
+    params = T.bench_params(is_mouse_dragging=dragging, mouse_radius=30.0, mouse_force=20.0)
+    with psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM) as sim:
+        for _ in range(steps):
+            sim.update(params)
+        got = sim.download_soa()
+    want, _ = T.oracle_update_soa(T.oracle_gen_uniform_soa(0, n), params, steps)
+    T.assert_same_f32(got, want, f"{steps} steps, dragging={dragging}")
+    if not dragging:
+        assert np.abs(want[3:]).max() < 1e-42        # the decay ended deep in the subnormals
+
+
+@pytest.mark.gpu
 def test_gpu_equals_oracle_on_random_cases():
     Sim = psim.HipParticleSimulation
     with Sim.new(1000, psim.GEN_UNIFORM) as sim:
