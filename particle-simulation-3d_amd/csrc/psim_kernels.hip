@@ -466,6 +466,7 @@ hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_firs
 // free of bank conflicts too: by 4 quads for the 16-byte reads of the export (banks
 // taken modulo 64 dwords), by 2 quads for the 16-byte writes of the import (modulo 32).
 
+template <bool NT>
 __global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint32_t first,
                                                                uint32_t n, f32x4 *aos)
 {
@@ -475,11 +476,11 @@ __global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint3
     const uint32_t i = base + t;
     if (i < n) {
         const uint32_t src = first + i;
-        const f32x2 pad = reinterpret_cast<const f32x2 *>(s.padding)[src];
-        tile[0][t] = f32x4{s.px[src], s.py[src], s.pz[src], pad[0]};
-        tile[1][t] = f32x4{s.vx[src], s.vy[src], s.vz[src], pad[1]};
-        tile[2][t] = reinterpret_cast<const f32x4 *>(s.color)[src];
-        tile[3][t] = reinterpret_cast<const f32x4 *>(s.initial_color)[src];
+        const f32x2 pad = ld<NT>(reinterpret_cast<const f32x2 *>(s.padding) + src);
+        tile[0][t] = f32x4{ld<NT>(s.px + src), ld<NT>(s.py + src), ld<NT>(s.pz + src), pad[0]};
+        tile[1][t] = f32x4{ld<NT>(s.vx + src), ld<NT>(s.vy + src), ld<NT>(s.vz + src), pad[1]};
+        tile[2][t] = ld<NT>(reinterpret_cast<const f32x4 *>(s.color) + src);
+        tile[3][t] = ld<NT>(reinterpret_cast<const f32x4 *>(s.initial_color) + src);
     }
     __syncthreads();
     const uint32_t live = (n - base) < PSIM_BLOCK ? (n - base) : PSIM_BLOCK;
@@ -487,10 +488,11 @@ __global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint3
     for (int k = 0; k < 4; ++k) {
         const uint32_t q = k * PSIM_BLOCK + t;                // quad index within the tile
         const uint32_t particle = q >> 2, field = q & 3u;
-        if (particle < live) aos[4ull * base + q] = tile[field][particle];
+        if (particle < live) st<NT>(aos + 4ull * base + q, tile[field][particle]);
     }
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint32_t first,
                                                                uint32_t n, const f32x4 *aos)
 {
@@ -502,28 +504,39 @@ __global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint3
     for (int k = 0; k < 4; ++k) {
         const uint32_t q = k * PSIM_BLOCK + t;
         const uint32_t particle = q >> 2, field = q & 3u;
-        if (particle < live) tile[field][particle] = aos[4ull * base + q];
+        if (particle < live) tile[field][particle] = ld<NT>(aos + 4ull * base + q);
     }
     __syncthreads();
     const uint32_t i = base + t;
     if (i < n) {
         const uint32_t dst = first + i;
         const f32x4 q0 = tile[0][t], q1 = tile[1][t];
-        s.px[dst] = q0[0]; s.py[dst] = q0[1]; s.pz[dst] = q0[2];
-        s.vx[dst] = q1[0]; s.vy[dst] = q1[1]; s.vz[dst] = q1[2];
-        reinterpret_cast<f32x2 *>(s.padding)[dst] = f32x2{q0[3], q1[3]};
-        reinterpret_cast<f32x4 *>(s.color)[dst] = tile[2][t];
-        reinterpret_cast<f32x4 *>(s.initial_color)[dst] = tile[3][t];
+        st<NT>(s.px + dst, q0[0]); st<NT>(s.py + dst, q0[1]); st<NT>(s.pz + dst, q0[2]);
+        st<NT>(s.vx + dst, q1[0]); st<NT>(s.vy + dst, q1[1]); st<NT>(s.vz + dst, q1[2]);
+        st<NT>(reinterpret_cast<f32x2 *>(s.padding) + dst, f32x2{q0[3], q1[3]});
+        st<NT>(reinterpret_cast<f32x4 *>(s.color) + dst, tile[2][t]);
+        st<NT>(reinterpret_cast<f32x4 *>(s.initial_color) + dst, tile[3][t]);
     }
 }
+
+// Launch shape of the transposes, measured at 100 M particles (GB/s of the 128 B per
+// particle moved): plain, 32 waves per CU 5.34 k (export) / 5.36 k (import); non-temporal
+// 5.5-5.6 k; non-temporal + LDS reservation 36864 B (3 workgroups = 12 waves per CU)
+// export 6.24 k, + 16384 B (4 workgroups) import 5.97 k; larger reservations fall off
+// (2 workgroups: 4.3 k / 2.8 k).  Small transfers stay plain: they are cache-resident.
+static bool aos_streaming(uint32_t n) { return (uint64_t)n * 128u > 400000000ull; }
 
 hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
                              hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
-    hipLaunchKernelGGL(export_aos_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, first, n,
-                       reinterpret_cast<f32x4 *>(aos));
+    if (aos_streaming(n))
+        hipLaunchKernelGGL(export_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK), 36864, stream,
+                           s, first, n, reinterpret_cast<f32x4 *>(aos));
+    else
+        hipLaunchKernelGGL(export_aos_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s,
+                           first, n, reinterpret_cast<f32x4 *>(aos));
     return hipGetLastError();
 }
 
@@ -532,8 +545,12 @@ hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
 {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
-    hipLaunchKernelGGL(import_aos_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, first, n,
-                       reinterpret_cast<const f32x4 *>(aos));
+    if (aos_streaming(n))
+        hipLaunchKernelGGL(import_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK), 16384, stream,
+                           s, first, n, reinterpret_cast<const f32x4 *>(aos));
+    else
+        hipLaunchKernelGGL(import_aos_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s,
+                           first, n, reinterpret_cast<const f32x4 *>(aos));
     return hipGetLastError();
 }
 
