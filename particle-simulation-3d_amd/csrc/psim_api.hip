@@ -250,8 +250,7 @@ int generate(psim_handle *h, int mode)
     const uint32_t gcount32 =
         (uint32_t)(h->global_count ? h->global_count : (uint64_t)h->count);
     if (mode == PSIM_GEN_UNIFORM) {
-        HIP_TRY(psim::launch_gen_uniform(h->soa, h->count, gfirst, kUniformSeed,
-                                         (uint32_t)h->num_cus * 16u, h->stream));
+        HIP_TRY(psim::launch_gen_uniform(h->soa, h->count, gfirst, kUniformSeed, h->stream));
         return PSIM_OK;
     }
     if (mode != PSIM_GEN_HOLLOW && mode != PSIM_GEN_FILLED)

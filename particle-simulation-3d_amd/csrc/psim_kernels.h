@@ -51,7 +51,7 @@ hipError_t launch_store_attractor(psim_attractor *dst, const psim_attractor &val
                                   hipStream_t stream);
 
 hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_first, uint64_t seed,
-                              uint32_t max_blocks, hipStream_t stream);
+                              hipStream_t stream);
 
 hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
                              hipStream_t stream);

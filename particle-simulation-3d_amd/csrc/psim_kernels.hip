@@ -419,6 +419,7 @@ __device__ __forceinline__ float unit_at(uint64_t seed, uint64_t counter)
 // Particle with global index g: position U[-50,50)^3, velocity U[-1,1)^3, colour
 // (pos/50 + 1) * 0.5 with alpha 1 (the reference's colour rule,
 // src/simulation/mod.rs:162-163), paddings 0.  One particle per lane.
+template <bool NT>
 __global__ void __launch_bounds__(PSIM_BLOCK) gen_uniform_kernel(SoaPtrs s, uint32_t n,
                                                                 uint64_t global_first,
                                                                 uint64_t seed)
@@ -432,24 +433,30 @@ __global__ void __launch_bounds__(PSIM_BLOCK) gen_uniform_kernel(SoaPtrs s, uint
             pos[c] = unit_at(seed, c0 + c) * 100.0f - 50.0f;
             vel[c] = unit_at(seed, c0 + 3 + c) * 2.0f - 1.0f;
         }
-        s.px[i] = pos[0]; s.py[i] = pos[1]; s.pz[i] = pos[2];
-        s.vx[i] = vel[0]; s.vy[i] = vel[1]; s.vz[i] = vel[2];
+        st<NT>(s.px + i, pos[0]); st<NT>(s.py + i, pos[1]); st<NT>(s.pz + i, pos[2]);
+        st<NT>(s.vx + i, vel[0]); st<NT>(s.vy + i, vel[1]); st<NT>(s.vz + i, vel[2]);
         const f32x4 col = {(pos[0] / 50.0f + 1.0f) * 0.5f, (pos[1] / 50.0f + 1.0f) * 0.5f,
                            (pos[2] / 50.0f + 1.0f) * 0.5f, 1.0f};
-        reinterpret_cast<f32x4 *>(s.color)[i] = col;
-        reinterpret_cast<f32x4 *>(s.initial_color)[i] = col;
-        reinterpret_cast<f32x2 *>(s.padding)[i] = f32x2{0.0f, 0.0f};
+        st<NT>(reinterpret_cast<f32x4 *>(s.color) + i, col);
+        st<NT>(reinterpret_cast<f32x4 *>(s.initial_color) + i, col);
+        st<NT>(reinterpret_cast<f32x2 *>(s.padding) + i, f32x2{0.0f, 0.0f});
     }
 }
 
+// One pass over the particles (like the update, faster than a capped grid-stride grid);
+// non-temporal stores and at most 3 resident workgroups per CU for states that do not fit
+// the Infinity Cache.
 hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_first, uint64_t seed,
-                              uint32_t max_blocks, hipStream_t stream)
+                              hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
-    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
-    hipLaunchKernelGGL(gen_uniform_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, n,
-                       global_first, seed);
+    const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    if ((uint64_t)n * 64u > 400000000ull)
+        hipLaunchKernelGGL(gen_uniform_kernel<true>, dim3(grid), dim3(PSIM_BLOCK), 53248, stream,
+                           s, n, global_first, seed);
+    else
+        hipLaunchKernelGGL(gen_uniform_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s,
+                           n, global_first, seed);
     return hipGetLastError();
 }
 
