@@ -156,6 +156,17 @@ int psim_update_multi(psim_handle *h, const psim_sim_params *params,
 int psim_update_multi_host(psim_handle *h, const psim_sim_params *params,
                            const psim_attractor *attractors_host, uint32_t n_attractors);
 
+/* Applies n_steps consecutive updates, params_host[0] first, with the state crossing
+ * HBM once per 64 steps instead of once per step: each lane loads its particles,
+ * steps them in registers with one parameter set after the other, and stores them.
+ * Particles never read other particles (src/simulation/cpu.rs:65-113), so the result
+ * is identical, bit for bit, to n_steps calls of psim_update with the same
+ * parameters.  No counterpart in the reference, whose caller learns a frame's
+ * delta_time only when the frame starts (src/app.rs:204-207); meant for replay and
+ * headless runs whose parameter stream is known ahead.  Asynchronous; params_host
+ * is copied before returning. */
+int psim_update_batch(psim_handle *h, const psim_sim_params *params_host, uint32_t n_steps);
+
 /* Stateless form of psim_update over caller-owned device arrays (each `count`
  * floats; `color` may be null when params->color_mode is 0, else 4*count
  * floats), enqueued on `hip_stream` (null = the default stream) of the current

@@ -83,6 +83,12 @@ public:
     // `fn update(&mut self, device, queue, encoder, params: &SimParams)`: asynchronous.
     void update(const SimParams &params) { check(psim_update(h_, &params)); }
 
+    // Several consecutive steps in one pass over the state (same result as update() each).
+    void update_batch(const std::vector<SimParams> &params)
+    {
+        check(psim_update_batch(h_, params.data(), static_cast<uint32_t>(params.size())));
+    }
+
     // Multi-attractor extension, list in host memory (<= 8) or device memory (<= 64).
     void update_multi(const SimParams &params, const std::vector<Attractor> &attractors)
     {

@@ -110,6 +110,7 @@ ABI = {
     "psim_create_shard": (c_int, [POINTER(_P), c_uint32, c_uint64, c_uint64, c_int, c_int]),
     "psim_destroy": (None, [_P]),
     "psim_update": (c_int, [_P, POINTER(SimParams)]),
+    "psim_update_batch": (c_int, [_P, POINTER(SimParams), c_uint32]),
     "psim_update_multi": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
     "psim_update_multi_host": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
     "psim_update_soa": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_uint32, POINTER(SimParams), _P]),
@@ -233,6 +234,12 @@ class HipParticleSimulation:
     # -- `fn update(&mut self, device, queue, encoder, params: &SimParams)`
     def update(self, params):
         _check(self._lib.psim_update(self._h, byref(params)))
+
+    def update_batch(self, params_list):
+        """Applies consecutive updates, one per SimParams in `params_list`, with the state
+        crossing HBM once per 64 steps; bit-identical to calling update() for each."""
+        arr = (SimParams * len(params_list))(*params_list)
+        _check(self._lib.psim_update_batch(self._h, arr, len(params_list)))
 
     def update_multi_device(self, params, attractors_device_ptr, n_attractors):
         """Multi-attractor step with the list in DEVICE memory (integer address)."""

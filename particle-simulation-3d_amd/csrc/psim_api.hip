@@ -428,6 +428,23 @@ PSIM_API int psim_update(psim_handle *h, const psim_sim_params *params)
     return PSIM_OK;
 }
 
+PSIM_API int psim_update_batch(psim_handle *h, const psim_sim_params *params_host,
+                               uint32_t n_steps)
+{
+    CHECK_HANDLE(h);
+    if (n_steps == 0) return PSIM_OK;
+    if (!params_host) return fail(PSIM_ERR_INVALID, "null params");
+    for (uint32_t done = 0; done < n_steps; done += PSIM_BATCH_STEPS) {
+        const uint32_t m = (n_steps - done) < PSIM_BATCH_STEPS ? (n_steps - done)
+                                                                : PSIM_BATCH_STEPS;
+        // a fused pass of >= 4 steps is VALU-bound: treat it like a long attractor list
+        // (no cap on resident waves)
+        HIP_TRY(psim::launch_update_batch(h->soa, h->count, params_host + done, m,
+                                          tuning_for(h->count, m, h->overrides), h->stream));
+    }
+    return PSIM_OK;
+}
+
 PSIM_API int psim_update_multi(psim_handle *h, const psim_sim_params *params,
                                const psim_attractor *attractors_device, uint32_t n_attractors)
 {

@@ -14,6 +14,7 @@
 #ifndef PSIM_UPDATE_BLOCK
 #define PSIM_UPDATE_BLOCK 64         /* the update kernel: single-wave workgroups */
 #endif
+#define PSIM_BATCH_STEPS 64u          /* parameter sets that fit one launch's kernel arguments */
 #define PSIM_KERNARG_ATTRACTORS 8u   /* attractor list size that fits the kernel arguments */
 
 namespace psim {
@@ -43,6 +44,10 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors);
 hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &p, int force,
                          const psim_attractor *attr_dev, const psim_attractor *attr_host,
                          uint32_t na, const LaunchTuning &t, hipStream_t stream);
+
+// nsteps <= PSIM_BATCH_STEPS consecutive single-attractor steps in one pass over the state.
+hipError_t launch_update_batch(const SoaPtrs &s, uint32_t n, const psim_sim_params *params,
+                               uint32_t nsteps, const LaunchTuning &t, hipStream_t stream);
 
 hipError_t launch_update_scalar(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
                                 uint32_t max_blocks, hipStream_t stream);

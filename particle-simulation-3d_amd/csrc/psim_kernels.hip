@@ -161,6 +161,34 @@ struct KernargAttractors {
 // bank slots per 16-lane group, so neither side has a bank conflict.
 #define PSIM_COLOUR_ROW 68   /* quads per LDS row: 64 + 4 of padding */
 
+// Stores the wave's 256 colour quads (`col` of every lane with `live`) to the colour array
+// of groups g0 .. g0+63 through the wave's LDS tile `t`, 1 KiB of consecutive bytes per
+// store instruction.  Must be reached by the whole wave.
+template <bool NT>
+__device__ __forceinline__ void store_colours_transposed(f32x4 (*t)[PSIM_COLOUR_ROW],
+                                                         f32x4 *col4, uint32_t g0, uint32_t lane,
+                                                         bool live, uint32_t ngroups,
+                                                         const f32x4 (&col)[4])
+{
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j][lane] = col[j];
+    }
+    // LDS operations of one wave execute in order; the fences only pin the compiler's
+    // ordering of the writes above against the reads below.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t q = k * 64u + lane;                        // quad within the wave's 4 KiB
+        const uint32_t src = q >> 2;                              // lane that computed it
+        if (g0 + src < ngroups) st<NT>(col4 + 4ull * g0 + q, t[q & 3u][src]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                              // a later call rewrites the tile
+}
+
 template <int CM, int FORCE, bool NT>
 __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, uint32_t n,
                                                                   psim_sim_params p,
@@ -222,24 +250,8 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
         }
         if constexpr (CM != 0) {
             __shared__ f32x4 tile[PSIM_UPDATE_BLOCK / 64][4][PSIM_COLOUR_ROW];
-            f32x4(*t)[PSIM_COLOUR_ROW] = tile[threadIdx.x >> 6];
-            if (live) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j][lane] = col[j];
-            }
-            // LDS operations of one wave execute in order; the fences only pin the
-            // compiler's ordering of the writes above against the reads below.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t q = k * 64u + lane;                // quad within the wave's 4 KiB
-                const uint32_t src = q >> 2;                      // lane that computed it
-                if (g0 + src < ngroups) st<NT>(col4 + 4ull * g0 + q, t[q & 3u][src]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                      // next trip rewrites the tile
+            store_colours_transposed<NT>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
+                                         col);
         }
     }
 
@@ -274,6 +286,118 @@ __global__ void __launch_bounds__(PSIM_BLOCK) update_kernel_scalar(SoaPtrs s, ui
             dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3];
         }
     }
+}
+
+// ---- several steps in one pass ----------------------------------------------
+//
+// Particles never read other particles, so k consecutive steps of one particle can be
+// taken back to back in registers: the state crosses HBM once instead of k times and the
+// kernel turns from HBM-bound into VALU-bound (~35-60 instructions per particle and step).
+// The k parameter sets travel in the kernel arguments (k <= PSIM_BATCH_STEPS = 64 fits the
+// 4 KiB argument segment; they are wave-uniform, so they are read with scalar loads).
+// The arithmetic of each step is exactly that of update_kernel, in the same order, so the
+// result equals k separate launches bit for bit.  Colour is written once, from the state
+// after step `colour_step` (the last step whose colour mode is 1 or 2; -1 = none): later
+// steps with mode 0 keep it (src/simulation/cpu.rs:106), earlier ones are overwritten.
+struct BatchParams {
+    psim_sim_params p[PSIM_BATCH_STEPS];
+};
+
+template <int N>
+__device__ __forceinline__ void step_batch(float (&a)[N], float (&b)[N], float (&c)[N],
+                                           float (&d)[N], float (&e)[N], float (&f)[N],
+                                           f32x4 (&col)[N], const BatchParams &bp,
+                                           uint32_t nsteps, int colour_step)
+{
+    for (uint32_t k = 0; k < nsteps; ++k) {
+        const psim_sim_params &p = bp.p[k];
+        if (p.is_mouse_dragging > 0) step<1, N>(a, b, c, d, e, f, p, nullptr, 0);
+        else step<0, N>(a, b, c, d, e, f, p, nullptr, 0);
+        if ((int)k == colour_step) {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                col[j] = p.color_mode == 1 ? colour<1>(a[j], b[j], c[j], d[j], e[j], f[j], p)
+                                           : colour<2>(a[j], b[j], c[j], d[j], e[j], f[j], p);
+        }
+    }
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs s, uint32_t n,
+                                                                        BatchParams bp,
+                                                                        uint32_t nsteps,
+                                                                        int colour_step)
+{
+    __shared__ f32x4 tile[PSIM_UPDATE_BLOCK / 64][4][PSIM_COLOUR_ROW];
+    f32x4 *px4 = reinterpret_cast<f32x4 *>(s.px), *py4 = reinterpret_cast<f32x4 *>(s.py),
+          *pz4 = reinterpret_cast<f32x4 *>(s.pz), *vx4 = reinterpret_cast<f32x4 *>(s.vx),
+          *vy4 = reinterpret_cast<f32x4 *>(s.vy), *vz4 = reinterpret_cast<f32x4 *>(s.vz);
+    f32x4 *col4 = reinterpret_cast<f32x4 *>(s.color);
+
+    const uint32_t ngroups = n >> 2;
+    const uint32_t stride = gridDim.x * PSIM_UPDATE_BLOCK;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t g0 = blockIdx.x * PSIM_UPDATE_BLOCK + (threadIdx.x & ~63u); g0 < ngroups;
+         g0 += stride) {
+        const uint32_t g = g0 + lane;
+        const bool live = g < ngroups;
+        f32x4 col[4];
+        if (live) {
+            f32x4 x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
+            f32x4 u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
+            float a[4], b[4], c[4], d[4], e[4], f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = x[j]; b[j] = y[j]; c[j] = z[j];
+                d[j] = u[j]; e[j] = v[j]; f[j] = w[j];
+            }
+            step_batch<4>(a, b, c, d, e, f, col, bp, nsteps, colour_step);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
+                u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
+            }
+            st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
+            st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
+        }
+        if (colour_step >= 0)                                     // uniform over the grid
+            store_colours_transposed<NT>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
+                                         col);
+    }
+
+    // Tail: particles 4*ngroups .. n-1.
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {
+        const uint32_t i = (ngroups << 2) + threadIdx.x;
+        float x[1] = {s.px[i]}, y[1] = {s.py[i]}, z[1] = {s.pz[i]};
+        float u[1] = {s.vx[i]}, v[1] = {s.vy[i]}, w[1] = {s.vz[i]};
+        f32x4 col[1];
+        step_batch<1>(x, y, z, u, v, w, col, bp, nsteps, colour_step);
+        s.px[i] = x[0]; s.py[i] = y[0]; s.pz[i] = z[0];
+        s.vx[i] = u[0]; s.vy[i] = v[0]; s.vz[i] = w[0];
+        if (colour_step >= 0) col4[i] = col[0];
+    }
+}
+
+hipError_t launch_update_batch(const SoaPtrs &s, uint32_t n, const psim_sim_params *params,
+                               uint32_t nsteps, const LaunchTuning &t, hipStream_t stream)
+{
+    if (n == 0 || nsteps == 0) return hipSuccess;
+    BatchParams bp;
+    memset(&bp, 0, sizeof(bp));
+    memcpy(bp.p, params, nsteps * sizeof(psim_sim_params));
+    int colour_step = -1;
+    for (uint32_t k = 0; k < nsteps; ++k)
+        if (params[k].color_mode == 1 || params[k].color_mode == 2) colour_step = (int)k;
+    const uint32_t grid = update_grid(n, t);
+    constexpr uint32_t used = (PSIM_UPDATE_BLOCK / 64) * 4 * PSIM_COLOUR_ROW * 16;
+    const uint32_t extra = t.reserve_lds > used ? t.reserve_lds - used : 0;
+    if (t.nontemporal)
+        hipLaunchKernelGGL(update_batch_kernel<true>, dim3(grid), dim3(PSIM_UPDATE_BLOCK), extra,
+                           stream, s, n, bp, nsteps, colour_step);
+    else
+        hipLaunchKernelGGL(update_batch_kernel<false>, dim3(grid), dim3(PSIM_UPDATE_BLOCK), extra,
+                           stream, s, n, bp, nsteps, colour_step);
+    return hipGetLastError();
 }
 
 // ---- launch dispatch -------------------------------------------------------

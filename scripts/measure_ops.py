@@ -86,6 +86,21 @@ def main():
               + ("   (host-synchronous call)" if sync_each else ""), flush=True)
 
 
+    # fused steps: k parameter sets per pass over the state
+    for k in (2, 4, 8, 16, 64, 256):
+        stream = [P(delta_time=0.016 + 1e-4 * (i % 7)) for i in range(k)]
+        times = []
+        for _ in range(args.rounds):
+            sim.update_batch(stream)
+            sim.sync()
+            sim.timer_start()
+            for _ in range(max(1, args.steps // 4)):
+                sim.update_batch(stream)
+            times.append(sim.timer_stop() / max(1, args.steps // 4))
+        med = statistics.median(times)
+        print(f"{'update batch of %d steps (fused passes)' % k:<48} | {med:9.4f} | "
+              f"{'':>9} | {n * k / med / 1e6:12.2f}   ({med / k * 1e3:.2f} us per step)", flush=True)
+
     # host transfers of the 64-byte records (device transposition + PCIe copy, synchronous)
     import time
     m = min(n, 10_000_000)
