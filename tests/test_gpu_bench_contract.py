@@ -1,0 +1,55 @@
+"""GPU test of bench.py's output contract: exactly one JSON line on stdout with the agreed
+fields (run at a reduced size so it takes seconds; the headline run uses the defaults)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import psim_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--steps", "5",
+                        "--warmup", "2", "--particles", "2000000", *extra],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must hold exactly one line, got {len(lines)}: {r.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def test_single_workload_line():
+    out = run_bench("--cpu-sample", "1000000", "--cpu-seconds", "1")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["unit"] == "particle-updates/s" and out["dtype"] == "f32"
+    assert out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["data"] == "synthetic"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    # value = particles x steps / wall time
+    assert abs(out["value"] - 2_000_000 * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-6
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert roof["algorithmic_bytes_per_launch"] == 48 * 2_000_000
+    assert roof["traffic"] is None            # the committed counters are for the 100 M size
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert cpu["unit"] == "particle-updates/s" and "particles" in cpu["sample"]
+
+
+def test_multi_workload_line():
+    out = run_bench("--workload", "multi", "--no-cpu-baseline")
+    assert out["n_gpus"] == 1 and "cpu_baseline" not in out
+    assert "all-gather" in out["config"]["sharding"]
+    assert out["value"] > 0
