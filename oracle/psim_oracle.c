@@ -8,8 +8,9 @@
  * PARITY UNPINNED BY THE REFERENCE: the reference is Rust (it cannot be built
  * here: no rustc/cargo) and ships no tests, golden vectors or fixtures for this
  * path.  The restatement is pinned instead by (1) an independent op-by-op
- * numpy-float32 derivation (tests/gen_golden.py) and (2) hand-derived known
- * answers (tests/test_oracle_golden.py), both committed with their vectors.
+ * numpy-float32 derivation (tests/gen_golden.py), compared on committed vectors
+ * and on seeded random sweeps (tests/test_random_parity.py), and (2) hand-derived
+ * known answers (tests/test_oracle_golden.py).
  *
  * What is restated (paths relative to the reference root):
  *   src/simulation/cpu.rs:51-59    parameter hoist, dragging = is_mouse_dragging > 0
