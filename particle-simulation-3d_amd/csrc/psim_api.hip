@@ -216,14 +216,73 @@ struct Xoshiro256pp {
         return r;
     }
     float next_f32() { return (float)((uint32_t)(next() >> 32) >> 8) * 0x1.0p-24f; }
+    void jump(uint64_t steps);
 };
 
-// Seeded uniform ball, src/simulation/mod.rs:168-188.  The stream is sequential:
-// `rng` must already stand at particle `first`.
-void gen_filled(psim_particle *out, Xoshiro256pp &rng, uint64_t n)
+// The state transition of Xoshiro256 is linear over GF(2), so `steps` calls of next()
+// equal one multiplication of the 256-bit state by T^steps.  XoshiroPowers holds the
+// images of the 256 basis states under T^(2^k), k = 0..39, built once by repeated
+// squaring; a jump applies the powers named by the bits of `steps`.  This lets every
+// host thread (and every shard) start at its own particle without drawing the numbers
+// before it.
+struct XoshiroPowers {
+    static constexpr int kBits = 40;        // jumps are < 3 * 2^32 draws
+    struct State { uint64_t w[4]; };
+    std::vector<State> col;                        // [k * 256 + bit]
+
+    static State apply(const State *m, const State &v)
+    {
+        State r{{0, 0, 0, 0}};
+        for (int word = 0; word < 4; ++word)
+            for (uint64_t bits = v.w[word]; bits; bits &= bits - 1) {
+                const State &c = m[word * 64 + __builtin_ctzll(bits)];
+                r.w[0] ^= c.w[0], r.w[1] ^= c.w[1], r.w[2] ^= c.w[2], r.w[3] ^= c.w[3];
+            }
+        return r;
+    }
+    XoshiroPowers() : col((size_t)kBits * 256)
+    {
+        for (int bit = 0; bit < 256; ++bit) {      // T itself: one step of each basis state
+            Xoshiro256pp g(0);
+            g.s[0] = g.s[1] = g.s[2] = g.s[3] = 0;
+            g.s[bit / 64] = 1ull << (bit % 64);
+            g.next();
+            col[bit] = State{{g.s[0], g.s[1], g.s[2], g.s[3]}};
+        }
+        for (int k = 1; k < kBits; ++k)            // T^(2^k) = (T^(2^(k-1)))^2
+            for (int bit = 0; bit < 256; ++bit)
+                col[(size_t)k * 256 + bit] =
+                    apply(&col[(size_t)(k - 1) * 256], col[(size_t)(k - 1) * 256 + bit]);
+    }
+    static const XoshiroPowers &get()
+    {
+        static const XoshiroPowers p;              // thread-safe one-time construction
+        return p;
+    }
+};
+
+void Xoshiro256pp::jump(uint64_t steps)
+{
+    if (steps < 4096) {                            // short hops: just draw
+        for (uint64_t k = 0; k < steps; ++k) next();
+        return;
+    }
+    const XoshiroPowers &p = XoshiroPowers::get();
+    XoshiroPowers::State v{{s[0], s[1], s[2], s[3]}};
+    for (int k = 0; k < XoshiroPowers::kBits; ++k)
+        if (steps >> k & 1) v = XoshiroPowers::apply(&p.col[(size_t)k * 256], v);
+    s[0] = v.w[0], s[1] = v.w[1], s[2] = v.w[2], s[3] = v.w[3];
+}
+
+// Seeded uniform ball, src/simulation/mod.rs:168-188.  One sequential random stream,
+// three draws per particle: particles [first, first + n) of the whole set are written,
+// the generator jumping to draw 3 * first.
+void gen_filled(psim_particle *out, uint64_t first, uint64_t n)
 {
     const float radius = 50.0f;
     const float pi = 3.14159265358979323846f;
+    Xoshiro256pp rng(kUniformSeed);
+    rng.jump(3 * first);
     for (uint64_t k = 0; k < n; ++k) {
         const float r = radius * cbrtf(rng.next_f32());
         const float theta = rng.next_f32() * 2.0f * pi;
@@ -262,31 +321,27 @@ int generate(psim_handle *h, int mode)
     } catch (const std::bad_alloc &) {
         return fail(PSIM_ERR_NOMEM, "host allocation for the generator failed");
     }
-    Xoshiro256pp rng(kUniformSeed);
-    if (mode == PSIM_GEN_FILLED)
-        for (uint64_t k = 0; k < 3 * gfirst; ++k) rng.next();   // skip earlier shards' draws
     for (uint64_t done = 0; done < h->count; done += chunk) {
         const uint64_t m = (h->count - done) < chunk ? (h->count - done) : chunk;
-        if (mode == PSIM_GEN_HOLLOW) {
-            // index-addressed: split the chunk over a few host threads
-            const unsigned hw = std::thread::hardware_concurrency();
-            const uint64_t workers = m < 65536 ? 1 : (hw == 0 ? 4 : (hw > 16 ? 16 : hw));
-            const uint64_t per = (m + workers - 1) / workers;
-            std::vector<std::thread> pool;
-            for (uint64_t w = 1; w < workers && w * per < m; ++w) {
-                const uint64_t lo = w * per, len = (m - lo) < per ? (m - lo) : per;
-                try {
-                    pool.emplace_back(gen_hollow, host.data() + lo, gcount32, gfirst + done + lo,
-                                      len);
-                } catch (...) {                                  // no thread: do it here
-                    gen_hollow(host.data() + lo, gcount32, gfirst + done + lo, len);
-                }
+        // both states are index-addressed: split the chunk over a few host threads
+        const auto fill = [=](psim_particle *dst, uint64_t first, uint64_t len) {
+            if (mode == PSIM_GEN_HOLLOW) gen_hollow(dst, gcount32, first, len);
+            else gen_filled(dst, first, len);
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const uint64_t workers = m < 65536 ? 1 : (hw == 0 ? 4 : (hw > 16 ? 16 : hw));
+        const uint64_t per = (m + workers - 1) / workers;
+        std::vector<std::thread> pool;
+        for (uint64_t w = 1; w < workers && w * per < m; ++w) {
+            const uint64_t lo = w * per, len = (m - lo) < per ? (m - lo) : per;
+            try {
+                pool.emplace_back(fill, host.data() + lo, gfirst + done + lo, len);
+            } catch (...) {                                      // no thread: do it here
+                fill(host.data() + lo, gfirst + done + lo, len);
             }
-            gen_hollow(host.data(), gcount32, gfirst + done, per < m ? per : m);
-            for (auto &t : pool) t.join();
-        } else {
-            gen_filled(host.data(), rng, m);                    // one sequential random stream
         }
+        fill(host.data(), gfirst + done, per < m ? per : m);
+        for (auto &t : pool) t.join();
         int rc = upload_aos_chunked(h, host.data(), done, m);
         if (rc != PSIM_OK) return rc;
     }

@@ -117,6 +117,17 @@ def main():
     print(f"{'upload AoS from host':<48} | {dt * 1e3:9.3f} | {64 * m / dt / 1e9:9.2f} | "
           f"{m / dt / 1e9:12.3f}   ({m} particles, pageable host memory)")
 
+    # the reference's two initial states (reset regenerates every particle)
+    for name, mode in (("reset hollow sphere", psim.GEN_HOLLOW), ("reset filled sphere", psim.GEN_FILLED)):
+        sim.reset(mode)
+        sim.sync()
+        t0 = time.perf_counter()
+        sim.reset(mode)
+        sim.sync()
+        dt = time.perf_counter() - t0
+        print(f"{name:<48} | {dt * 1e3:9.3f} | {64 * n / dt / 1e9:9.2f} | {n / dt / 1e9:12.3f}"
+              f"   ({n} particles)")
+
 
 if __name__ == "__main__":
     main()

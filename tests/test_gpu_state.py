@@ -63,10 +63,20 @@ def test_hollow_generator_matches_oracle(n):
         T.assert_particles_equal(sim.download_aos(), T.oracle_gen_hollow_aos(n), f"hollow {n}")
 
 
-@pytest.mark.parametrize("n", [1, 1000, 100_000])
+@pytest.mark.parametrize("n", [1, 1000, 100_000, 2_500_001])
 def test_filled_generator_matches_oracle(n):
+    # from 65 536 particles on, host threads each jump the random stream to their slice
     with Sim.new(n, psim.GEN_FILLED) as sim:
         T.assert_particles_equal(sim.download_aos(), T.oracle_gen_filled_aos(0, n), f"filled {n}")
+
+
+def test_filled_shard_far_into_the_stream():
+    """A shard starts 6e8 draws into the one sequential stream: the library jumps there
+    (the state transition is linear over GF(2)), the oracle draws its way."""
+    first = 200_000_000
+    with Sim.new_shard(70_000, first, 250_000_000, psim.GEN_FILLED) as shard:
+        T.assert_particles_equal(shard.download_aos(), T.oracle_gen_filled_aos(first, 70_000),
+                                 "filled shard at 2e8")
 
 
 def test_default_configuration_of_the_app():
