@@ -221,6 +221,15 @@ void psim_set_paused(psim_handle *h, int paused);
 int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n);
 int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint64_t first, uint64_t n);
 
+/* Page-locked host memory for the copies above.  The CPU backend of the
+ * reference keeps a host-side `Vec<Particle>` that it hands to the renderer every
+ * frame (src/simulation/cpu.rs:8, :116-120); a caller that stages frames through
+ * host memory the same way should take that buffer from here: copies into and out
+ * of page-locked memory run at the full host-link rate, copies of pageable memory
+ * at a fraction of it.  Free with psim_host_free (NULL is allowed). */
+int  psim_host_alloc(void **out, uint64_t bytes);
+void psim_host_free(void *ptr);
+
 /* Copies positions and velocities of particles [first, first+n) to / from HOST
  * memory as six consecutive arrays of n floats: px | py | pz | vx | vy | vz.
  * Synchronous. */

@@ -57,6 +57,31 @@ private:
     int code_;
 };
 
+// Page-locked host array of 64-byte records: the host-side `Vec<Particle>` of a caller
+// that stages frames through host memory (cpu.rs:8, :116-120), at the host link's rate.
+class PinnedParticles {
+public:
+    explicit PinnedParticles(size_t n) : n_(n)
+    {
+        void *p = nullptr;
+        const int rc = psim_host_alloc(&p, static_cast<uint64_t>(n) * sizeof(Particle));
+        if (rc != PSIM_OK) throw Error(rc, psim_last_error());
+        p_ = static_cast<Particle *>(p);
+    }
+    ~PinnedParticles() { psim_host_free(p_); }
+    PinnedParticles(const PinnedParticles &) = delete;
+    PinnedParticles &operator=(const PinnedParticles &) = delete;
+    Particle *data() { return p_; }
+    const Particle *data() const { return p_; }
+    size_t size() const { return n_; }
+    Particle &operator[](size_t i) { return p_[i]; }
+    const Particle &operator[](size_t i) const { return p_[i]; }
+
+private:
+    Particle *p_ = nullptr;
+    size_t n_ = 0;
+};
+
 class HipParticleSimulation {
 public:
     // `fn new(device, initial_particle_count, surface_format, generation_mode) -> Self`
@@ -141,6 +166,15 @@ public:
         return out;
     }
     void upload(const std::vector<Particle> &particles, uint64_t first = 0)
+    {
+        check(psim_upload_aos(h_, particles.data(), first, particles.size()));
+    }
+    // The same through a page-locked array (no allocation per frame).
+    void download(PinnedParticles &out, uint64_t first = 0)
+    {
+        check(psim_download_aos(h_, out.data(), first, out.size()));
+    }
+    void upload(const PinnedParticles &particles, uint64_t first = 0)
     {
         check(psim_upload_aos(h_, particles.data(), first, particles.size()));
     }

@@ -124,6 +124,8 @@ ABI = {
     "psim_set_paused": (None, [_P, c_int]),
     "psim_download_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_upload_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_host_alloc": (c_int, [POINTER(_P), c_uint64]),
+    "psim_host_free": (None, [_P]),
     "psim_download_soa": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_upload_soa": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_export_aos_device": (c_int, [_P, _P, c_uint64, c_uint64]),
@@ -291,11 +293,17 @@ class HipParticleSimulation:
         return view
 
     # -- particle data in and out
-    def download_aos(self, first=0, n=None):
+    def download_aos(self, first=0, n=None, out=None):
+        """Particles [first, first + n) as 64-byte records; `out` (for instance an array
+        from pinned_empty) is filled and returned when given."""
         n = self.get_particle_count() - first if n is None else n
-        out = np.empty(n, dtype=PARTICLE_DTYPE)
+        if out is None:
+            out = np.empty(n, dtype=PARTICLE_DTYPE)
+        elif out.dtype != PARTICLE_DTYPE or out.ndim != 1 or len(out) < n \
+                or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous PARTICLE_DTYPE array of at least n records")
         _check(self._lib.psim_download_aos(self._h, out.ctypes.data_as(c_void_p), first, n))
-        return out
+        return out[:n]
 
     def upload_aos(self, particles, first=0):
         arr = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
@@ -366,6 +374,32 @@ def store_attractor(dst_device_ptr, attractor, stream=0):
     arr = _as_attractors(attractor).reshape(-1)[:1]
     _check(load_library().psim_store_attractor(c_void_p(dst_device_ptr),
                                                arr.ctypes.data_as(c_void_p), c_void_p(stream)))
+
+
+class _PinnedBlock:
+    """Owns one psim_host_alloc allocation; freed when the last array over it goes."""
+
+    def __init__(self, nbytes):
+        self._lib = load_library()
+        ptr = c_void_p()
+        _check(self._lib.psim_host_alloc(byref(ptr), nbytes))
+        self.ptr = ptr.value
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._lib.psim_host_free(c_void_p(self.ptr))
+            self.ptr = None
+
+
+def pinned_empty(n, dtype=PARTICLE_DTYPE):
+    """An uninitialised 1-D numpy array of `n` records in page-locked host memory
+    (psim_host_alloc): download_aos(out=...) / upload_aos() run at the host link's rate."""
+    dtype = np.dtype(dtype)
+    nbytes = int(n) * dtype.itemsize
+    block = _PinnedBlock(nbytes)
+    raw = (ctypes.c_char * max(nbytes, 1)).from_address(block.ptr)
+    raw._owner = block                       # the numpy array keeps `raw`, `raw` keeps the block
+    return np.frombuffer(raw, dtype=np.uint8, count=nbytes).view(dtype)
 
 
 def version():

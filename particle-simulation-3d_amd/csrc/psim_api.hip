@@ -300,8 +300,6 @@ void gen_filled(psim_particle *out, uint64_t first, uint64_t n)
     }
 }
 
-int upload_aos_chunked(psim_handle *h, const psim_particle *src, uint64_t first, uint64_t n);
-
 // Fills particles [0, count) of the handle with `mode`.
 int generate(psim_handle *h, int mode)
 {
@@ -314,37 +312,62 @@ int generate(psim_handle *h, int mode)
     }
     if (mode != PSIM_GEN_HOLLOW && mode != PSIM_GEN_FILLED)
         return fail(PSIM_ERR_INVALID, "unknown generation mode %d", mode);
+    if (h->count == 0) return PSIM_OK;
+    // Two page-locked chunks: while chunk k travels to the device and is transposed
+    // there, the host threads already fill chunk k + 1.
     const uint64_t chunk = 1u << 20;
-    std::vector<psim_particle> host;
-    try {
-        host.resize((size_t)(h->count < chunk ? h->count : chunk));
-    } catch (const std::bad_alloc &) {
-        return fail(PSIM_ERR_NOMEM, "host allocation for the generator failed");
-    }
-    for (uint64_t done = 0; done < h->count; done += chunk) {
+    static_assert(2 * (1u << 20) <= kStageParticles, "two chunks fit the device staging buffer");
+    const uint64_t slot_particles = h->count < chunk ? h->count : chunk;
+    const int slots = h->count > chunk ? 2 : 1;
+    int rc = ensure_stage(h);
+    if (rc != PSIM_OK) return rc;
+    struct Staging {
+        psim_particle *host = nullptr;
+        hipEvent_t done[2] = {nullptr, nullptr};
+        ~Staging()
+        {
+            if (host) (void)hipHostFree(host);
+            for (hipEvent_t e : done)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } st;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st.host),
+                          (size_t)(slot_particles * slots) * sizeof(psim_particle),
+                          hipHostMallocDefault));
+    for (int b = 0; b < slots; ++b)
+        HIP_TRY(hipEventCreateWithFlags(&st.done[b], hipEventDisableTiming));
+    const auto fill = [=](psim_particle *dst, uint64_t first, uint64_t len) {
+        if (mode == PSIM_GEN_HOLLOW) gen_hollow(dst, gcount32, first, len);
+        else gen_filled(dst, first, len);
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    uint64_t nchunk = 0;
+    for (uint64_t done = 0; done < h->count; done += chunk, ++nchunk) {
         const uint64_t m = (h->count - done) < chunk ? (h->count - done) : chunk;
+        const int b = (int)(nchunk % (uint64_t)slots);
+        psim_particle *host = st.host + (uint64_t)b * slot_particles;
+        psim_particle *stage = h->aos_stage + (uint64_t)b * slot_particles;
+        if (nchunk >= (uint64_t)slots) HIP_TRY(hipEventSynchronize(st.done[b]));   // slot free again
         // both states are index-addressed: split the chunk over a few host threads
-        const auto fill = [=](psim_particle *dst, uint64_t first, uint64_t len) {
-            if (mode == PSIM_GEN_HOLLOW) gen_hollow(dst, gcount32, first, len);
-            else gen_filled(dst, first, len);
-        };
-        const unsigned hw = std::thread::hardware_concurrency();
         const uint64_t workers = m < 65536 ? 1 : (hw == 0 ? 4 : (hw > 16 ? 16 : hw));
         const uint64_t per = (m + workers - 1) / workers;
         std::vector<std::thread> pool;
         for (uint64_t w = 1; w < workers && w * per < m; ++w) {
             const uint64_t lo = w * per, len = (m - lo) < per ? (m - lo) : per;
             try {
-                pool.emplace_back(fill, host.data() + lo, gfirst + done + lo, len);
+                pool.emplace_back(fill, host + lo, gfirst + done + lo, len);
             } catch (...) {                                      // no thread: do it here
-                fill(host.data() + lo, gfirst + done + lo, len);
+                fill(host + lo, gfirst + done + lo, len);
             }
         }
-        fill(host.data(), gfirst + done, per < m ? per : m);
+        fill(host, gfirst + done, per < m ? per : m);
         for (auto &t : pool) t.join();
-        int rc = upload_aos_chunked(h, host.data(), done, m);
-        if (rc != PSIM_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(stage, host, (size_t)m * sizeof(psim_particle),
+                               hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)done, (uint32_t)m, stage, h->stream));
+        HIP_TRY(hipEventRecord(st.done[b], h->stream));
     }
+    HIP_TRY(hipStreamSynchronize(h->stream));                    // before the staging goes away
     return PSIM_OK;
 }
 
@@ -662,6 +685,24 @@ PSIM_API int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint
     if (n == 0) return PSIM_OK;
     if (!src_host) return fail(PSIM_ERR_INVALID, "null source");
     return upload_aos_chunked(h, src_host, first, n);
+}
+
+PSIM_API int psim_host_alloc(void **out, uint64_t bytes)
+{
+    if (!out) return fail(PSIM_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(PSIM_ERR_NO_DEVICE, "no HIP device: page-locked memory needs one");
+    void *p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, bytes ? (size_t)bytes : 1, hipHostMallocPortable));
+    *out = p;
+    return PSIM_OK;
+}
+
+PSIM_API void psim_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 PSIM_API int psim_download_soa(psim_handle *h, float *dst_host, uint64_t first, uint64_t n)

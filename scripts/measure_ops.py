@@ -117,6 +117,17 @@ def main():
     print(f"{'upload AoS from host':<48} | {dt * 1e3:9.3f} | {64 * m / dt / 1e9:9.2f} | "
           f"{m / dt / 1e9:12.3f}   ({m} particles, pageable host memory)")
 
+    pinned = psim.pinned_empty(m)
+    for name, fn in (("download AoS to host", lambda: sim.download_aos(0, m, out=pinned)),
+                     ("upload AoS from host", lambda: sim.upload_aos(pinned, 0))):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        print(f"{name:<48} | {dt * 1e3:9.3f} | {64 * m / dt / 1e9:9.2f} | {m / dt / 1e9:12.3f}"
+              f"   ({m} particles, page-locked host memory)")
+    del pinned
+
     # the reference's two initial states (reset regenerates every particle)
     for name, mode in (("reset hollow sphere", psim.GEN_HOLLOW), ("reset filled sphere", psim.GEN_FILLED)):
         sim.reset(mode)

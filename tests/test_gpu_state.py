@@ -206,6 +206,28 @@ def test_reference_generators_shard_consistently(mode):
         assert shard.download_aos().tobytes() == ref[6000:9000].tobytes()
 
 
+def test_page_locked_host_buffers():
+    n = 300_001
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        sim.update(T.bench_params(mouse_radius=50.0, color_mode=1))
+        want = sim.download_aos()
+        pinned = psim.pinned_empty(n)
+        got = sim.download_aos(out=pinned)
+        assert got.tobytes() == want.tobytes()
+        part = sim.download_aos(1000, 5000, out=pinned)          # a slice into a larger buffer
+        assert len(part) == 5000 and part.tobytes() == want[1000:6000].tobytes()
+        pinned[:] = want[::-1]                                   # upload from page-locked memory
+        sim.upload_aos(pinned)
+        assert sim.download_aos().tobytes() == want[::-1].tobytes()
+        with pytest.raises(ValueError):
+            sim.download_aos(out=np.empty(10, dtype=psim.PARTICLE_DTYPE))
+    empty = psim.pinned_empty(0)
+    assert len(empty) == 0
+    lib = psim.load_library()
+    lib.psim_host_free(None)                                     # NULL is allowed
+    assert lib.psim_host_alloc(None, 64) == 1
+
+
 def test_uniform_shard_beyond_u32_indices():
     first = 5_000_000_000
     with Sim.new_shard(1000, first, 8_000_000_000, psim.GEN_UNIFORM) as shard:
