@@ -99,11 +99,55 @@ __global__ void update_u(Arrays s, uint32_t ngroups)
     }
 }
 
+// Tiled layout: one buffer, the six components of a wave's 64 groups stored back to back
+// (6 KiB contiguous per wave), so the in-place update is ONE read stream and ONE write
+// stream over the same addresses instead of twelve.
+template <bool NT>
+__global__ void update_tiled(f32x4 *buf, uint32_t ngroups)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t g = wave * 64u + lane;
+    if (g >= ngroups) return;
+    f32x4 *p = buf + (size_t)wave * 384u + lane;
+    f32x4 r[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) r[c] = ld<NT>(p + 64 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = r[0][j], y = r[1][j], z = r[2][j], u = r[3][j], v = r[4][j], w = r[5][j];
+        step1(x, y, z, u, v, w);
+        r[0][j] = x; r[1][j] = y; r[2][j] = z; r[3][j] = u; r[4][j] = v; r[5][j] = w;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) st<NT>(p + 64 * c, r[c]);
+}
+
+// In-place float4 scale: the ceiling of a single read-modify-write stream.
+template <bool NT>
+__global__ void inplace4(f32x4 *a, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) st<NT>(a + i, ld<NT>(a + i) * 0.99f);
+}
+
 template <bool NT>
 __global__ void copy4(const f32x4 *src, f32x4 *dst, size_t n4)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n4) st<NT>(dst + i, ld<NT>(src + i));
+}
+
+// benchmark-like contents: positions uniform in [-50, 50), velocities in [-1, 1)
+__global__ void fill_random(float *a, size_t n, float scale, float offset, uint32_t salt)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + salt;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    a[i] = (float)(z >> 40) * 0x1.0p-24f * scale + offset;
 }
 
 static float time_launches(hipStream_t s, int reps, const std::function<void()> &launch)
@@ -169,6 +213,9 @@ int main(int argc, char **argv)
         CHECK(hipMalloc((void **)&src, n4 * 16));
         CHECK(hipMalloc((void **)&dst, n4 * 16));
         CHECK(hipMemsetAsync(src, 0, n4 * 16, s));
+        if (argc > 2)
+            hipLaunchKernelGGL(fill_random, dim3((unsigned)((n4 * 4 + 255) / 256)), dim3(256), 0, s,
+                               (float *)src, n4 * 4, 100.0f, -50.0f, 7u);
         for (int nt = 0; nt < 2; ++nt)
             for (int lds : {0, 23040, 65536}) {
                 const int block = lds == 23040 ? 64 : 256;
@@ -184,8 +231,55 @@ int main(int argc, char **argv)
         CHECK(hipFree(dst));
     }
 
+    // tiled layout and the in-place ceiling
+    {
+        const uint32_t waves = (ngroups + 63u) / 64u;
+        const size_t n4 = (size_t)waves * 384u;
+        f32x4 *buf;
+        CHECK(hipMalloc((void **)&buf, n4 * 16));
+        CHECK(hipMemsetAsync(buf, 0, n4 * 16, s));
+        if (argc > 2)
+            hipLaunchKernelGGL(fill_random, dim3((unsigned)((n4 * 4 + 255) / 256)), dim3(256), 0, s,
+                               (float *)buf, n4 * 4, 100.0f, -50.0f, 9u);
+        for (int nt = 0; nt < 2; ++nt)
+            for (int lds : {0, 16384, 23040, 32768}) {
+                const int block = lds ? 64 : 256;
+                const float ms = time_launches(s, 20, [&] {
+                    const uint32_t grid = (uint32_t)((n4 + block - 1) / block);
+                    if (nt) hipLaunchKernelGGL(inplace4<true>, dim3(grid), dim3(block), lds, s, buf, n4);
+                    else hipLaunchKernelGGL(inplace4<false>, dim3(grid), dim3(block), lds, s, buf, n4);
+                });
+                printf("inplace nt=%d block=%4d lds=%6d : %.4f ms  %7.1f GB/s\n", nt, block, lds, ms,
+                       bytes / ms / 1e6);
+            }
+        for (int nt = 0; nt < 2; ++nt)
+            for (int lds : {0, 12288, 16384, 20480, 23040, 26624, 32768, 40960}) {
+                const int block = 64;
+                const float ms = time_launches(s, 20, [&] {
+                    if (nt) hipLaunchKernelGGL(update_tiled<true>, dim3(waves), dim3(block), lds, s, buf, ngroups);
+                    else hipLaunchKernelGGL(update_tiled<false>, dim3(waves), dim3(block), lds, s, buf, ngroups);
+                });
+                printf("tiled  nt=%d block=%4d lds=%6d (%3d waves/CU) : %.4f ms  %7.1f GB/s\n", nt, block,
+                       lds, lds ? std::min(32, 163840 / lds) : 32, ms, bytes / ms / 1e6);
+                fflush(stdout);
+            }
+        CHECK(hipFree(buf));
+    }
+
     for (int lds : {0, 16384, 23040, 26624, 32768, 40960, 53248})
         run_update<1, true>(s, arr, ngroups, 64, lds, bytes);
+    if (argc > 2) {        // any second argument: repeat with benchmark-like random contents
+        for (int c = 0; c < 6; ++c) {
+            const size_t nf = (size_t)ngroups * 4;
+            hipLaunchKernelGGL(fill_random, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s,
+                               (float *)arr.a[c], nf, c < 3 ? 100.0f : 2.0f, c < 3 ? -50.0f : -1.0f,
+                               (uint32_t)c);
+        }
+        printf("random contents (about 2 %% of the particles in range):\n");
+        for (int lds : {16384, 20480, 23040, 26624, 32768})
+            run_update<1, true>(s, arr, ngroups, 64, lds, bytes);
+        return 0;
+    }
     for (int lds : {23040, 26624, 32768, 40960, 53248, 81920})
         run_update<2, true>(s, arr, ngroups, 64, lds, bytes);
     for (int lds : {32768, 40960, 53248, 81920, 131072})
