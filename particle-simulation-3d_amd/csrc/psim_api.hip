@@ -83,7 +83,7 @@ psim::LaunchTuning tuning_for(uint32_t n, uint32_t n_attractors, const TuningOve
 {
     psim::LaunchTuning t = psim::choose_tuning(n, n_attractors);
     if (o.nontemporal >= 0) t.nontemporal = o.nontemporal ? 1 : 0;
-    if (o.reserve_lds >= 0) t.reserve_lds = (uint32_t)o.reserve_lds;
+    if (o.reserve_lds >= 0) t.reserve_lds = t.reserve_lds_colour = (uint32_t)o.reserve_lds;
     if (o.max_blocks >= 0) t.max_blocks = (uint32_t)o.max_blocks;
     return t;
 }

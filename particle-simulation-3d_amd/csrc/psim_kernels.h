@@ -32,6 +32,7 @@ struct LaunchTuning {
     uint32_t max_blocks;   // 0 = one pass (grid covers every group), else grid-stride cap
     int nontemporal;       // non-temporal loads/stores of the state arrays
     uint32_t reserve_lds;  // untouched dynamic LDS bytes per workgroup: caps workgroups per CU
+    uint32_t reserve_lds_colour;   // the same for colour modes 1/2 (one more write stream)
 };
 
 uint32_t update_grid(uint32_t n, const LaunchTuning &t);

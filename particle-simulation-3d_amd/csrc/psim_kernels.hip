@@ -413,7 +413,8 @@ static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params 
     // The reservation counts the LDS the kernel itself declares.
     constexpr uint32_t used = (CM != 0 ? (PSIM_UPDATE_BLOCK / 64) * 4 * PSIM_COLOUR_ROW * 16 : 0) +
                               (FORCE == 2 ? PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) : 0);
-    const uint32_t extra = t.reserve_lds > used ? t.reserve_lds - used : 0;
+    const uint32_t want = CM != 0 ? t.reserve_lds_colour : t.reserve_lds;
+    const uint32_t extra = want > used ? want - used : 0;
     if (t.nontemporal)
         hipLaunchKernelGGL((update_kernel<CM, FORCE, true>), dim3(grid), dim3(PSIM_UPDATE_BLOCK),
                            extra, stream, s, n, p, attr_dev, na, ka);
@@ -470,7 +471,11 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     LaunchTuning t;
     t.max_blocks = 0;
     t.nontemporal = state_bytes > 400000000ull ? 1 : 0;
-    t.reserve_lds = (state_bytes >= 96000000ull && n_attractors < 4) ? 23040u : 0u;
+    const bool cap = state_bytes >= 96000000ull && n_attractors < 4;
+    t.reserve_lds = cap ? 23040u : 0u;
+    // With the colour store as a thirteenth stream 6 workgroups per CU are better than 7:
+    // 6.25-6.34 k against 6.13-6.17 k GB/s of the 64 B stream (100 M particles).
+    t.reserve_lds_colour = cap ? (t.nontemporal ? 26624u : 23040u) : 0u;
     return t;
 }
 
