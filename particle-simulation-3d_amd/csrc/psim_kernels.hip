@@ -472,7 +472,9 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     t.max_blocks = 0;
     t.nontemporal = state_bytes > 400000000ull ? 1 : 0;
     const bool cap = state_bytes >= 96000000ull && n_attractors < 4;
-    t.reserve_lds = cap ? 23040u : 0u;
+    // 7 workgroups per CU up to 250 M particles (6.47-6.50 k); at 500 M and 1 G particles
+    // 6 are better (6.42-6.44 k against 6.32-6.34 k).
+    t.reserve_lds = cap ? (state_bytes >= 9600000000ull ? 26624u : 23040u) : 0u;
     // With the colour store as a thirteenth stream 6 workgroups per CU are better than 7:
     // 6.25-6.34 k against 6.13-6.17 k GB/s of the 64 B stream (100 M particles).
     t.reserve_lds_colour = cap ? (t.nontemporal ? 26624u : 23040u) : 0u;
