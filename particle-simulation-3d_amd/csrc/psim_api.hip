@@ -105,6 +105,7 @@ struct psim_handle {
     psim::SoaPtrs soa = {};
     uint64_t *checksum_dev = nullptr;          // 8 x u64 inside the slab
     psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
+    uint32_t stage_particles = 0;              // its size
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     TuningOverrides overrides;
 };
@@ -150,11 +151,21 @@ int allocate(psim_handle *h, uint32_t capacity)
     return PSIM_OK;
 }
 
+// The device-side AoS staging buffer: the whole set when it is small (<= 1 Mi particles),
+// otherwise the fixed 4 Mi-particle chunk.  Grows when a resize made the set larger.
 int ensure_stage(psim_handle *h)
 {
-    if (h->aos_stage) return PSIM_OK;
+    const uint32_t want = h->capacity > (1u << 20) ? kStageParticles : h->capacity;
+    if (h->aos_stage && h->stage_particles >= want) return PSIM_OK;
+    if (h->aos_stage) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->aos_stage);
+        h->aos_stage = nullptr;
+        h->stage_particles = 0;
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->aos_stage),
-                      (size_t)kStageParticles * sizeof(psim_particle)));
+                      (size_t)want * sizeof(psim_particle)));
+    h->stage_particles = want;
     return PSIM_OK;
 }
 
