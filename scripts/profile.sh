@@ -21,4 +21,16 @@ for C in FETCH_SIZE WRITE_SIZE; do
         > "$OUT/pmc_${C}_bench.json" 2> "$OUT/pmc_$C.err" || { echo "pmc pass $C failed"; tail -5 "$OUT/pmc_$C.err"; exit 1; }
     echo "pmc pass $C done"
 done
-find "$OUT" -name "*.csv" | head -20
+
+# every kernel of the path once each (scripts/profile_ops.py): durations, then counters
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ops_trace" -o trace \
+    -- python3 "$REPO/scripts/profile_ops.py" \
+    > "$OUT/ops_config.json" 2> "$OUT/ops_trace.err" || { echo "ops kernel-trace pass failed"; tail -5 "$OUT/ops_trace.err"; exit 1; }
+echo "ops kernel-trace pass done"
+for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d "$OUT/ops_pmc_$C" -o pmc \
+        -- python3 "$REPO/scripts/profile_ops.py" --launches 3 \
+        > /dev/null 2> "$OUT/ops_pmc_$C.err" || { echo "ops pmc pass $C failed"; tail -5 "$OUT/ops_pmc_$C.err"; exit 1; }
+    echo "ops pmc pass $C done"
+done
+find "$OUT" -name "*.csv" | head -30
