@@ -704,6 +704,7 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
 
 // out[k] += sum over particles of the bit pattern of component k.  Integer sums
 // commute, so the result does not depend on the schedule.
+template <bool NT>
 __global__ void __launch_bounds__(PSIM_BLOCK) checksum_kernel(SoaPtrs s, uint32_t n,
                                                              unsigned long long *out)
 {
@@ -715,7 +716,7 @@ __global__ void __launch_bounds__(PSIM_BLOCK) checksum_kernel(SoaPtrs s, uint32_
     for (uint64_t g = (uint64_t)blockIdx.x * PSIM_BLOCK + threadIdx.x; g < ngroups; g += stride) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const f32x4 q = reinterpret_cast<const f32x4 *>(arr[k])[g];
+            const f32x4 q = ld<NT>(reinterpret_cast<const f32x4 *>(arr[k]) + g);
             acc[k] += (uint64_t)__float_as_uint(q[0]) + __float_as_uint(q[1]) +
                       __float_as_uint(q[2]) + __float_as_uint(q[3]);
         }
@@ -748,8 +749,12 @@ hipError_t launch_checksum(const SoaPtrs &s, uint32_t n, uint64_t *out_dev, uint
     if (e != hipSuccess || n == 0) return e;
     uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
     if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
-    hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, n,
-                       reinterpret_cast<unsigned long long *>(out_dev));
+    if ((uint64_t)n * 24u > 400000000ull)      // streaming: the state does not fit the caches
+        hipLaunchKernelGGL(checksum_kernel<true>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, n,
+                           reinterpret_cast<unsigned long long *>(out_dev));
+    else
+        hipLaunchKernelGGL(checksum_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s, n,
+                           reinterpret_cast<unsigned long long *>(out_dev));
     return hipGetLastError();
 }
 
