@@ -230,6 +230,13 @@ int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint64_t firs
 int  psim_host_alloc(void **out, uint64_t bytes);
 void psim_host_free(void *ptr);
 
+/* psim_download_aos without the wait: enqueues the transposition and the copy on the
+ * handle's stream and returns.  `dst_pinned` must come from psim_host_alloc and stay
+ * untouched until psim_sync; updates enqueued afterwards run behind the copy and do not
+ * disturb it.  This is how a frame loop that stages through host memory
+ * (src/simulation/cpu.rs:116-120) overlaps the transfer of frame k with its own work. */
+int psim_download_aos_async(psim_handle *h, psim_particle *dst_pinned, uint64_t first, uint64_t n);
+
 /* Copies positions and velocities of particles [first, first+n) to / from HOST
  * memory as six consecutive arrays of n floats: px | py | pz | vx | vy | vz.
  * Synchronous. */

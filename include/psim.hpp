@@ -174,6 +174,11 @@ public:
     {
         check(psim_download_aos(h_, out.data(), first, out.size()));
     }
+    // Enqueue only; the records are valid after sync().
+    void download_async(PinnedParticles &out, uint64_t first = 0)
+    {
+        check(psim_download_aos_async(h_, out.data(), first, out.size()));
+    }
     void upload(const PinnedParticles &particles, uint64_t first = 0)
     {
         check(psim_upload_aos(h_, particles.data(), first, particles.size()));

@@ -124,6 +124,7 @@ ABI = {
     "psim_set_paused": (None, [_P, c_int]),
     "psim_download_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_upload_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_download_aos_async": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_host_alloc": (c_int, [POINTER(_P), c_uint64]),
     "psim_host_free": (None, [_P]),
     "psim_download_soa": (c_int, [_P, _P, c_uint64, c_uint64]),
@@ -303,6 +304,16 @@ class HipParticleSimulation:
                 or not out.flags.c_contiguous:
             raise ValueError("out must be a contiguous PARTICLE_DTYPE array of at least n records")
         _check(self._lib.psim_download_aos(self._h, out.ctypes.data_as(c_void_p), first, n))
+        return out[:n]
+
+    def download_aos_async(self, out, first=0, n=None):
+        """Enqueues the download into `out` (an array from pinned_empty) and returns; the
+        records are valid after sync()."""
+        n = self.get_particle_count() - first if n is None else n
+        if out.dtype != PARTICLE_DTYPE or out.ndim != 1 or len(out) < n \
+                or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous PARTICLE_DTYPE array of at least n records")
+        _check(self._lib.psim_download_aos_async(self._h, out.ctypes.data_as(c_void_p), first, n))
         return out[:n]
 
     def upload_aos(self, particles, first=0):

@@ -667,9 +667,12 @@ PSIM_API void psim_set_paused(psim_handle *h, int paused)
 
 // ---- particle data in and out -------------------------------------------------
 
-PSIM_API int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n)
+namespace {
+
+// Transposes chunk after chunk into the staging buffer and copies it out, all in stream
+// order (the next chunk's transposition waits for the previous chunk's copy by itself).
+int enqueue_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n)
 {
-    CHECK_HANDLE(h);
     int rc = check_range(h, first, n);
     if (rc != PSIM_OK) return rc;
     if (n == 0) return PSIM_OK;
@@ -682,9 +685,26 @@ PSIM_API int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t
                                         h->stream));
         HIP_TRY(hipMemcpyAsync(dst_host + done, h->aos_stage, (size_t)m * sizeof(psim_particle),
                                hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return PSIM_OK;
+}
+
+}  // namespace
+
+PSIM_API int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n)
+{
+    CHECK_HANDLE(h);
+    int rc = enqueue_download_aos(h, dst_host, first, n);
+    if (rc != PSIM_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_download_aos_async(psim_handle *h, psim_particle *dst_pinned, uint64_t first,
+                                     uint64_t n)
+{
+    CHECK_HANDLE(h);
+    return enqueue_download_aos(h, dst_pinned, first, n);
 }
 
 PSIM_API int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint64_t first,

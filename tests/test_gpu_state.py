@@ -228,6 +228,25 @@ def test_page_locked_host_buffers():
     assert lib.psim_host_alloc(None, 64) == 1
 
 
+def test_async_download_is_a_snapshot_in_stream_order():
+    """Frame k is enqueued for download, then further updates are enqueued behind it: after
+    sync the buffer holds frame k, the device holds frame k + 3."""
+    n = 5_000_000                                  # two staging chunks
+    params = T.bench_params(mouse_radius=50.0)
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        sim.update(params)
+        want_k = sim.download_aos()
+        frame = psim.pinned_empty(n)
+        got = sim.download_aos_async(frame)
+        for _ in range(3):
+            sim.update(params)
+        sim.sync()
+        assert got.tobytes() == want_k.tobytes()
+        T.assert_particles_equal(sim.download_aos()[:200_000],
+                                 T.oracle_update_aos(want_k[:200_000].copy(), params, 3),
+                                 "updates behind the async download")
+
+
 def test_uniform_shard_beyond_u32_indices():
     first = 5_000_000_000
     with Sim.new_shard(1000, first, 8_000_000_000, psim.GEN_UNIFORM) as shard:
