@@ -10,6 +10,7 @@
 // usage: frame_loop <count> <generation 0|1|2> <frames> <params_out> <particles_out>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "psim.hpp"
@@ -76,6 +77,12 @@ int main(int argc, char **argv)
         }
         sim.sync();
         const std::vector<psim::Particle> out = sim.download();
+        // the same frame through a page-locked array, enqueued and awaited
+        psim::PinnedParticles frame(out.size());
+        sim.download_async(frame);
+        sim.sync();
+        if (!out.empty() && std::memcmp(frame.data(), out.data(), out.size() * sizeof(psim::Particle)) != 0)
+            return 5;
 
         FILE *f = std::fopen(argv[4], "wb");
         if (!f) return 4;
