@@ -108,6 +108,12 @@ def main():
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this benchmark has no CPU path")
+    # PSIM_BENCH_REHEARSAL=1 (tests only): several ranks share the GPUs that exist and talk
+    # over gloo, so the N > 1 control flow can be run on a one-GPU machine.  The numbers of
+    # such a run mean nothing.
+    rehearsal = os.environ.get("PSIM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the process group is used even for one rank
     distributed = world > 1 or args.workload == "multi" or "RANK" in os.environ
@@ -116,11 +122,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            if rehearsal:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     psim = importlib.import_module("particle-simulation-3d_amd")
     n = args.particles
@@ -154,7 +166,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     barrier()

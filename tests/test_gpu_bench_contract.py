@@ -48,6 +48,29 @@ def test_single_workload_line():
     assert cpu["unit"] == "particle-updates/s" and "particles" in cpu["sample"]
 
 
+def test_two_rank_control_flow_rehearsal():
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one
+    process per rank), rehearsed on one GPU: both ranks share it and talk over gloo.  Checks
+    the aggregation (value over all ranks, max-over-ranks time, one line from rank 0), not
+    the speed."""
+    env = dict(os.environ, PSIM_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    n = 1_000_000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(T.ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "2", "--particles", str(n)],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:1000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "cpu_baseline" not in out
+    assert out["config"]["total_particles"] == 2 * n and out["config"]["particles_per_gpu"] == n
+    assert abs(out["value"] - 2 * n * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-6
+
+
 def test_multi_workload_line():
     out = run_bench("--workload", "multi", "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and "cpu_baseline" not in out
