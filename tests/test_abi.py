@@ -37,6 +37,48 @@ def test_python_binding_covers_every_declared_symbol():
     assert sorted(psim.ABI) == declared_symbols()
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/psim.h compiles as C99 (and as C++ through psim.hpp / psim_caller.hpp), the
+    record sizes are the reference's (mod.rs:52-67, 86-98), and a C program links against the
+    library with nothing but the header."""
+    import subprocess
+    src = tmp_path / "abi_check.c"
+    src.write_text('''
+#include <stddef.h>
+#include <stdio.h>
+#include "psim.h"
+_Static_assert(sizeof(psim_sim_params) == 48, "SimParams");
+_Static_assert(offsetof(psim_sim_params, mouse_position) == 32, "SimParams");
+_Static_assert(sizeof(psim_particle) == 64, "Particle");
+_Static_assert(offsetof(psim_particle, initial_color) == 48, "Particle");
+_Static_assert(sizeof(psim_attractor) == 32, "attractor");
+int main(void) {
+    psim_handle *h = NULL;
+    int rc = psim_create(&h, 16, PSIM_GEN_UNIFORM, 0);
+    printf("%s|%d|%s\\n", psim_version(), rc, rc ? psim_last_error() : "");
+    if (h) psim_destroy(h);
+    return 0;
+}
+''')
+    libdir = os.path.dirname(psim.LIBRARY_PATH)
+    exe = tmp_path / "abi_check"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror",
+                           "-I", os.path.join(T.ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lpsim_hip", f"-Wl,-rpath,{libdir}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True)
+    version, rc, message = out.strip().split("|")
+    assert "gfx950" in version
+    if not T.gpu_available():
+        assert int(rc) == 4 and "no CPU path" in message
+    cpp = tmp_path / "hpp_check.cpp"
+    cpp.write_text('#include "psim.hpp"\n#include "psim_caller.hpp"\n'
+                   'int main() { psim::CallerState s; psim::FrameInput in{}; in.screen_width = 1;'
+                   ' in.screen_height = 1; return s.frame(in).damping == 0.99f ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(T.ROOT, "include"), str(cpp)])
+
+
 def test_library_exports_nothing_else_public():
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", psim.LIBRARY_PATH], text=True)
