@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Full-size parity soak: the benchmark state (default 100 M particles) is stepped through a
+scripted parameter stream on the GPU (single updates and fused batches, through the C ABI)
+and by the CPU oracle; device checksums are compared with the oracle's every `--every` steps
+and the whole state value by value at the end.  The bar is 1e-5 relative; the comparison is
+for bit equality and reports the largest relative error if that fails.
+
+The oracle is the checker here, never the thing measured."""
+import argparse
+import ctypes
+import importlib
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+psim = importlib.import_module("particle-simulation-3d_amd")
+import psim_testlib as T  # noqa: E402
+
+
+def stream(steps):
+    """A drag across the cloud with changing frame times, gravity and attractor settings."""
+    out = []
+    for i in range(steps):
+        ang = 2 * math.pi * i / 240.0
+        out.append(psim.SimParams(
+            delta_time=(0.016, 0.0175, 0.01525, 0.033)[i % 4],
+            gravity=0.0 if i < steps // 3 else 2.5,
+            color_mode=0,
+            mouse_force=5.0 if (i // 64) % 2 == 0 else 60.0,
+            mouse_radius=10.0 if (i // 96) % 2 == 0 else 35.0,
+            is_mouse_dragging=0 if (i // 40) % 5 == 4 else 1,
+            damping=0.99,
+            max_dist_for_color=50.0,
+            mouse_position=(30.0 * math.cos(ang), 30.0 * math.sin(ang), 48.0 - 0.2 * i)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--particles", type=int, default=100_000_000)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--every", type=int, default=50)
+    args = ap.parse_args()
+    n = args.particles
+    lib = T.load_oracle()
+    threads = int(lib.psim_oracle_max_threads())
+    params = stream(args.steps)
+
+    sim = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
+    ref = T.oracle_gen_uniform_soa(0, n)
+    ptr = [T._ptr(ref[k]) for k in range(6)]
+    print(f"particles={n} steps={args.steps} oracle threads={threads}", flush=True)
+    assert sim.checksum() == T.oracle_checksum_soa(ref), "initial state differs"
+
+    t_gpu = t_cpu = 0.0
+    done = 0
+    while done < args.steps:
+        m = min(args.every, args.steps - done)
+        chunk = params[done:done + m]
+        t0 = time.perf_counter()
+        if (done // args.every) % 2 == 0:
+            for p in chunk:
+                sim.update(p)
+        else:
+            sim.update_batch(chunk)                     # the same steps, fused
+        got = sim.checksum()
+        t_gpu += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for p in chunk:
+            lib.psim_oracle_update_soa(*ptr, None, n, ctypes.byref(p), None, 0, threads)
+        t_cpu += time.perf_counter() - t0
+        want = T.oracle_checksum_soa(ref)
+        done += m
+        ok = got == want
+        print(f"step {done:5d}: checksums {'equal' if ok else 'DIFFER'}  "
+              f"(gpu {t_gpu:6.2f} s, oracle {t_cpu:6.2f} s)", flush=True)
+        if not ok:
+            break
+
+    final = sim.download_soa()
+    same = bool(np.array_equal(final.view(np.uint32), ref.view(np.uint32)))
+    nan = int(np.isnan(ref).sum())
+    if not same and nan:                                # NaN payloads are not compared
+        both = np.isnan(final) & np.isnan(ref)
+        same = bool(np.array_equal(np.where(both, 0, final.view(np.uint32)),
+                                   np.where(both, 0, ref.view(np.uint32))))
+    print(f"final state: {'bit-identical' if same else 'DIFFERENT'} over {6 * n} values "
+          f"({nan} NaN)", flush=True)
+    if not same:
+        print(f"max relative error {T.max_rel_err(final, ref):.3e} (bar 1e-5)")
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
