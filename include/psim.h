@@ -111,6 +111,16 @@ enum {
     PSIM_METHOD_HIP            = 2
 };
 
+/* What a step with color_mode other than 1 or 2 does to the colour.  The reference's
+ * two backends disagree: the CPU path keeps the current colour
+ * (src/simulation/cpu.rs:106), the compute shader resets it to the initial colour
+ * (src/shaders/compute.wgsl:75-77, 90-92).  They differ only after modes 1/2 have been
+ * visited. */
+enum {
+    PSIM_COLOR_KEEP  = 0,  /* CPU-path semantics (default: the CPU path is the oracle) */
+    PSIM_COLOR_RESET = 1   /* compute-shader semantics */
+};
+
 /* ---- lifecycle ------------------------------------------------------------ */
 
 /* Replaces `ParticleSimulation::new` (src/simulation/mod.rs:22-29; call sites
@@ -211,6 +221,16 @@ int psim_method(const psim_handle *h);
  * caller honours. */
 int  psim_is_paused(const psim_handle *h);
 void psim_set_paused(psim_handle *h, int paused);
+
+/* Selects PSIM_COLOR_KEEP (src/simulation/cpu.rs:106) or PSIM_COLOR_RESET
+ * (src/shaders/compute.wgsl:75-77, 90-92) for the updates that follow.  Under RESET the
+ * colour array equals the initial colours after every step whose mode is not 1 or 2 -- as
+ * with the shader -- but the copy is made only when colours were actually changed since
+ * (by a mode 1/2 step, an upload, or a caller holding the raw pointers of
+ * psim_device_soa), so steady mode-0 stepping still moves 48 B per particle.  The stateless
+ * psim_update_soa has no initial colours and always keeps. */
+int psim_set_color_semantics(psim_handle *h, int semantics);
+int psim_color_semantics(const psim_handle *h);
 
 /* ---- particle data in and out (replaces `get_particle_buffer`,
  *      src/simulation/mod.rs:44, whose consumer is the renderer's 64-byte

@@ -154,6 +154,11 @@ public:
         check(psim_reset(h_, static_cast<int>(generation_mode)));
     }
 
+    // Colour of a step in a mode other than 1/2: PSIM_COLOR_KEEP (cpu.rs:106, default) or
+    // PSIM_COLOR_RESET (compute.wgsl:75-77, 90-92).
+    void set_color_semantics(int semantics) { check(psim_set_color_semantics(h_, semantics)); }
+    int get_color_semantics() const { return psim_color_semantics(h_); }
+
     // `fn is_paused(&self) -> bool` / `fn set_paused(&mut self, paused: bool)`
     bool is_paused() const { return psim_is_paused(h_) != 0; }
     void set_paused(bool paused) { psim_set_paused(h_, paused ? 1 : 0); }

@@ -100,6 +100,7 @@ class SoaView(ctypes.Structure):
 GEN_HOLLOW, GEN_FILLED, GEN_UNIFORM = 0, 1, 2
 # `enum SimulationMethod` (mod.rs:9-13) + this backend.
 METHOD_CPU, METHOD_COMPUTE_SHADER, METHOD_HIP = 0, 1, 2
+COLOR_KEEP, COLOR_RESET = 0, 1      # cpu.rs:106 / compute.wgsl:75-77
 MAX_ATTRACTORS = 64
 MAX_HOST_ATTRACTORS = 8
 
@@ -122,6 +123,8 @@ ABI = {
     "psim_method": (c_int, [_P]),
     "psim_is_paused": (c_int, [_P]),
     "psim_set_paused": (None, [_P, c_int]),
+    "psim_set_color_semantics": (c_int, [_P, c_int]),
+    "psim_color_semantics": (c_int, [_P]),
     "psim_download_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_upload_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_download_aos_async": (c_int, [_P, _P, c_uint64, c_uint64]),
@@ -286,6 +289,14 @@ class HipParticleSimulation:
 
     def set_paused(self, paused):
         self._lib.psim_set_paused(self._h, 1 if paused else 0)
+
+    # -- colour of a step in a mode other than 1/2: keep (cpu.rs:106) or reset to the
+    #    initial colour (compute.wgsl:75-77, 90-92)
+    def set_color_semantics(self, semantics):
+        _check(self._lib.psim_set_color_semantics(self._h, int(semantics)))
+
+    def get_color_semantics(self):
+        return self._lib.psim_color_semantics(self._h)
 
     # -- `fn get_particle_buffer(&self) -> &wgpu::Buffer`: the device pointers
     def get_particle_buffer(self):

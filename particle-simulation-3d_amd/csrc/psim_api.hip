@@ -101,7 +101,9 @@ struct psim_handle {
     uint64_t global_count = 0;   // 0 = not a shard: the set is [0, count)
     int generation_mode = PSIM_GEN_HOLLOW;
     bool paused = false;
-    void *slab = nullptr;        // one allocation, carved into `soa`
+    int colour_semantics = PSIM_COLOR_KEEP;
+    bool colours_changed = false;   // colour may differ from initial_colour
+    void *slab = nullptr;       // one allocation, carved into `soa`
     psim::SoaPtrs soa = {};
     uint64_t *checksum_dev = nullptr;          // 8 x u64 inside the slab
     psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
@@ -314,6 +316,7 @@ void gen_filled(psim_particle *out, uint64_t first, uint64_t n)
 // Fills particles [0, count) of the handle with `mode`.
 int generate(psim_handle *h, int mode)
 {
+    h->colours_changed = false;                  // every generator writes colour = initial colour
     const uint64_t gfirst = h->global_first;
     const uint32_t gcount32 =
         (uint32_t)(h->global_count ? h->global_count : (uint64_t)h->count);
@@ -475,6 +478,25 @@ int create_impl(psim_handle **out, uint32_t count, uint64_t global_first, uint64
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+bool is_colour_mode(uint32_t m) { return m == 1u || m == 2u; }
+
+// Colour bookkeeping after an update whose LAST step ran with `last_mode`, `wrote` telling
+// whether any step of it computed colours.  Under PSIM_COLOR_RESET the compute shader's
+// rule applies (compute.wgsl:75-77, 90-92): a step in any other mode leaves colour ==
+// initial_colour.  The shader rewrites the colour every step; the visible state is the
+// same when the copy is made only after colours have actually been changed.
+int settle_colours(psim_handle *h, uint32_t last_mode, bool wrote)
+{
+    if (wrote) h->colours_changed = true;
+    if (h->colour_semantics == PSIM_COLOR_RESET && !is_colour_mode(last_mode) &&
+        h->colours_changed && h->count) {
+        HIP_TRY(hipMemcpyAsync(h->soa.color, h->soa.initial_color, (size_t)h->count * 16u,
+                               hipMemcpyDeviceToDevice, h->stream));
+        h->colours_changed = false;
+    }
+    return PSIM_OK;
+}
+
 }  // namespace
 
 // ---- lifecycle --------------------------------------------------------------
@@ -514,7 +536,7 @@ PSIM_API int psim_update(psim_handle *h, const psim_sim_params *params)
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, nullptr, 0,
                                 tuning_for(h->count, 1, h->overrides),
                                 h->stream));
-    return PSIM_OK;
+    return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
 }
 
 PSIM_API int psim_update_batch(psim_handle *h, const psim_sim_params *params_host,
@@ -531,7 +553,9 @@ PSIM_API int psim_update_batch(psim_handle *h, const psim_sim_params *params_hos
         HIP_TRY(psim::launch_update_batch(h->soa, h->count, params_host + done, m,
                                           tuning_for(h->count, m, h->overrides), h->stream));
     }
-    return PSIM_OK;
+    bool wrote = false;
+    for (uint32_t k = 0; k < n_steps; ++k) wrote = wrote || is_colour_mode(params_host[k].color_mode);
+    return settle_colours(h, params_host[n_steps - 1].color_mode, wrote);
 }
 
 PSIM_API int psim_update_multi(psim_handle *h, const psim_sim_params *params,
@@ -549,7 +573,7 @@ PSIM_API int psim_update_multi(psim_handle *h, const psim_sim_params *params,
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, attractors_device, nullptr,
                                 n_attractors, tuning_for(h->count, n_attractors, h->overrides),
                                 h->stream));
-    return PSIM_OK;
+    return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
 }
 
 PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *params,
@@ -565,7 +589,7 @@ PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *param
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, attractors_host,
                                 n_attractors, tuning_for(h->count, n_attractors, h->overrides),
                                 h->stream));
-    return PSIM_OK;
+    return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
 }
 
 PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *vy, float *vz,
@@ -715,6 +739,7 @@ PSIM_API int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint
     if (rc != PSIM_OK) return rc;
     if (n == 0) return PSIM_OK;
     if (!src_host) return fail(PSIM_ERR_INVALID, "null source");
+    h->colours_changed = true;                   // the caller's colours, whatever they are
     return upload_aos_chunked(h, src_host, first, n);
 }
 
@@ -788,13 +813,29 @@ PSIM_API int psim_import_aos_device(psim_handle *h, const psim_particle *src_dev
     if (n == 0) return PSIM_OK;
     if (!src_device || !aligned16(src_device))
         return fail(PSIM_ERR_INVALID, "AoS device buffer must be non-null and 16-byte aligned");
+    h->colours_changed = true;
     HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)first, (uint32_t)n, src_device, h->stream));
     return PSIM_OK;
+}
+
+PSIM_API int psim_set_color_semantics(psim_handle *h, int semantics)
+{
+    CHECK_HANDLE(h);
+    if (semantics != PSIM_COLOR_KEEP && semantics != PSIM_COLOR_RESET)
+        return fail(PSIM_ERR_INVALID, "unknown colour semantics %d", semantics);
+    h->colour_semantics = semantics;
+    return PSIM_OK;
+}
+
+PSIM_API int psim_color_semantics(const psim_handle *h)
+{
+    return h ? h->colour_semantics : PSIM_COLOR_KEEP;
 }
 
 PSIM_API int psim_device_soa(psim_handle *h, psim_soa_view *view)
 {
     if (!h || !view) return fail(PSIM_ERR_INVALID, "null argument");
+    h->colours_changed = true;                   // the caller may write through these pointers
     view->px = h->soa.px; view->py = h->soa.py; view->pz = h->soa.pz;
     view->vx = h->soa.vx; view->vy = h->soa.vy; view->vz = h->soa.vz;
     view->color = h->soa.color;

@@ -228,6 +228,41 @@ def test_page_locked_host_buffers():
     assert lib.psim_host_alloc(None, 64) == 1
 
 
+def test_compute_shader_colour_semantics():
+    """PSIM_COLOR_RESET: a step in a mode other than 1/2 leaves colour == initial colour
+    (compute.wgsl:75-77, 90-92); the default keeps the current colour (cpu.rs:106).  The
+    expected state is the CPU oracle's with that one rule applied after every such step."""
+    n = 70_001
+    modes = [0, 1, 1, 0, 0, 2, 7, 1, 2, 0]
+    for fused in (False, True):
+        with Sim.new(n, psim.GEN_UNIFORM) as sim:
+            assert sim.get_color_semantics() == psim.COLOR_KEEP
+            sim.set_color_semantics(psim.COLOR_RESET)
+            assert sim.get_color_semantics() == psim.COLOR_RESET
+            state = sim.download_aos()
+            stream = [T.bench_params(mouse_radius=50.0, color_mode=m) for m in modes]
+            for i, p in enumerate(stream):
+                state = T.oracle_update_aos(state, p, 1)
+                if p.color_mode not in (1, 2):
+                    state["color"] = state["initial_color"]
+                if not fused:
+                    sim.update(p)
+                    T.assert_particles_equal(sim.download_aos(), state, f"reset semantics, step {i}")
+            if fused:
+                sim.update_batch(stream)
+                T.assert_particles_equal(sim.download_aos(), state, "reset semantics, fused")
+            # uploaded colours count as changed: the next mode-0 step resets them
+            custom = state.copy()
+            custom["color"] = 0.25
+            sim.upload_aos(custom)
+            sim.update(stream[0])
+            want = T.oracle_update_aos(custom, stream[0], 1)
+            want["color"] = want["initial_color"]
+            T.assert_particles_equal(sim.download_aos(), want, "reset after upload")
+            with pytest.raises(psim.PsimError):
+                sim.set_color_semantics(5)
+
+
 def test_async_download_is_a_snapshot_in_stream_order():
     """Frame k is enqueued for download, then further updates are enqueued behind it: after
     sync the buffer holds frame k, the device holds frame k + 3."""
