@@ -112,6 +112,18 @@ def test_null_arguments_are_rejected_without_a_device():
     assert lib.psim_particle_count(None) == 0
     assert lib.psim_is_paused(None) == 0
     lib.psim_destroy(None)                                      # no-op
+    assert lib.psim_host_alloc(None, 64) == 1
+    lib.psim_host_free(None)                                    # no-op
+    assert lib.psim_set_color_semantics(None, 1) == 1
+    assert lib.psim_color_semantics(None) == 0
+    assert lib.psim_download_aos_async(None, None, 0, 0) == 1
+
+
+@pytest.mark.skipif(T.gpu_available(), reason="a GPU is present")
+def test_page_locked_memory_needs_a_device():
+    with pytest.raises(psim.PsimError) as e:
+        psim.pinned_empty(16)
+    assert e.value.code == 4
 
 
 @pytest.mark.skipif(T.gpu_available(), reason="a GPU is present")
