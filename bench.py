@@ -203,7 +203,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "psim::update_kernel<colour 0, single attractor>",
+                "kernel": ("psim::update_kernel<colour 0, single attractor>"
+                           if args.workload == "single" else
+                           "psim::update_kernel<colour 0, attractor list staged in LDS> "
+                           "(launch_ms here also holds the waits for the per-step all-gather)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
