@@ -660,9 +660,21 @@ __global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint3
 // Launch shape of the transposes, measured at 100 M particles (GB/s of the 128 B per
 // particle moved): plain, 32 waves per CU 5.34 k (export) / 5.36 k (import); non-temporal
 // 5.5-5.6 k; non-temporal + LDS reservation 36864 B (3 workgroups = 12 waves per CU)
-// export 6.24 k, + 16384 B (4 workgroups) import 5.97 k; larger reservations fall off
-// (2 workgroups: 4.3 k / 2.8 k).  Small transfers stay plain: they are cache-resident.
+// export 6.3-6.4 k, + 20480 B (4 workgroups) import 6.33-6.35 k; larger reservations fall
+// off (2 workgroups: 4.3 k / 2.8 k).  The import is sensitive beyond the workgroup count:
+// 16384 B and 24064 B also leave 4 workgroups per CU but reach only 6.0-6.1 k, repeatably.
+// Small transfers stay plain: they are cache-resident.
 static bool aos_streaming(uint32_t n) { return (uint64_t)n * 128u > 400000000ull; }
+
+// Experiments only: PSIM_AOS_RESERVE overrides the LDS reservation of both transposes.
+static uint32_t aos_reserve(uint32_t automatic)
+{
+    static const int v = [] {
+        const char *e = getenv("PSIM_AOS_RESERVE");
+        return e && *e ? atoi(e) : -1;
+    }();
+    return v >= 0 ? (uint32_t)v : automatic;
+}
 
 hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
                              hipStream_t stream)
@@ -670,7 +682,8 @@ hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
     if (aos_streaming(n))
-        hipLaunchKernelGGL(export_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK), 36864, stream,
+        hipLaunchKernelGGL(export_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK),
+                           aos_reserve(36864), stream,
                            s, first, n, reinterpret_cast<f32x4 *>(aos));
     else
         hipLaunchKernelGGL(export_aos_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s,
@@ -684,7 +697,8 @@ hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
     if (aos_streaming(n))
-        hipLaunchKernelGGL(import_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK), 16384, stream,
+        hipLaunchKernelGGL(import_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK),
+                           aos_reserve(20480), stream,
                            s, first, n, reinterpret_cast<const f32x4 *>(aos));
     else
         hipLaunchKernelGGL(import_aos_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s,
