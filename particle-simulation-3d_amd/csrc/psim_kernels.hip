@@ -39,6 +39,42 @@ __device__ __forceinline__ void st(T *p, T v)
     else *p = v;
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Streaming store of one element (4, 8 or 16 bytes) per lane: the wave writes elements
+// first .. first+63 of `array`, lanes at or past element `limit` are dropped by the bounds
+// check of the buffer descriptor.  The store carries the cache-policy bits nt + sc1, which
+// the compiler does not emit for a plain or a non-temporal global store; measured on the
+// 100 M-particle update (GB/s of the 48 B stream, loads nt): stores nt 6.46 k, stores
+// sc0 sc1 6.51 k, stores nt sc1 6.57 k, plain stores 5.86 k.  `first` must be the same for
+// every lane of the wave.
+#define PSIM_BUFFER_WORD3 0x00020000   /* gfx9 family: raw buffer, 32-bit data format */
+#define PSIM_POLICY_NT_SC1 18          /* aux bits of the raw buffer intrinsics: 1 sc0, 2 nt, 16 sc1 */
+template <typename T>
+__device__ __forceinline__ void st_stream(T *array, uint64_t first, uint64_t limit,
+                                          uint32_t lane, T v)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "dword, dwordx2, dwordx4");
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)first);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(first >> 32));
+    const uint64_t f = ((uint64_t)hi << 32) | lo;
+    const uint64_t left = limit > f ? limit - f : 0;
+    const uint32_t bytes = (uint32_t)(left < 64 ? left : 64) * (uint32_t)sizeof(T);
+    const __amdgpu_buffer_rsrc_t r =
+        __builtin_amdgcn_make_buffer_rsrc(array + f, 0, (int)bytes, PSIM_BUFFER_WORD3);
+    const uint32_t off = lane * (uint32_t)sizeof(T);
+    if constexpr (sizeof(T) == 16)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0,
+                                               PSIM_POLICY_NT_SC1);
+    else if constexpr (sizeof(T) == 8)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0,
+                                              PSIM_POLICY_NT_SC1);
+    else
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0,
+                                              PSIM_POLICY_NT_SC1);
+}
+
 // ---- the per-particle step (src/simulation/cpu.rs:66-112) -------------------
 
 // glam Vec3::length: sqrt((x*x + y*y) + z*z).
@@ -183,7 +219,11 @@ __device__ __forceinline__ void store_colours_transposed(f32x4 (*t)[PSIM_COLOUR_
     for (int k = 0; k < 4; ++k) {
         const uint32_t q = k * 64u + lane;                        // quad within the wave's 4 KiB
         const uint32_t src = q >> 2;                              // lane that computed it
-        if (g0 + src < ngroups) st<NT>(col4 + 4ull * g0 + q, t[q & 3u][src]);
+        if constexpr (NT) {
+            st_stream(col4, 4ull * g0 + 64u * k, 4ull * ngroups, lane, t[q & 3u][src]);
+        } else {
+            if (g0 + src < ngroups) st<NT>(col4 + 4ull * g0 + q, t[q & 3u][src]);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                              // a later call rewrites the tile
@@ -240,8 +280,14 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
                 x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
                 u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
             }
-            st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
-            st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
+            if constexpr (NT) {
+                st_stream(px4, g0, ngroups, lane, x); st_stream(py4, g0, ngroups, lane, y);
+                st_stream(pz4, g0, ngroups, lane, z); st_stream(vx4, g0, ngroups, lane, u);
+                st_stream(vy4, g0, ngroups, lane, v); st_stream(vz4, g0, ngroups, lane, w);
+            } else {
+                st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
+                st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
+            }
             if constexpr (CM != 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -357,8 +403,14 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs
                 x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
                 u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
             }
-            st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
-            st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
+            if constexpr (NT) {
+                st_stream(px4, g0, ngroups, lane, x); st_stream(py4, g0, ngroups, lane, y);
+                st_stream(pz4, g0, ngroups, lane, z); st_stream(vx4, g0, ngroups, lane, u);
+                st_stream(vy4, g0, ngroups, lane, v); st_stream(vz4, g0, ngroups, lane, w);
+            } else {
+                st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
+                st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
+            }
         }
         if (colour_step >= 0)                                     // uniform over the grid
             store_colours_transposed<NT>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
@@ -413,7 +465,10 @@ static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params 
     // The reservation counts the LDS the kernel itself declares.
     constexpr uint32_t used = (CM != 0 ? (PSIM_UPDATE_BLOCK / 64) * 4 * PSIM_COLOUR_ROW * 16 : 0) +
                               (FORCE == 2 ? PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) : 0);
-    const uint32_t want = CM != 0 ? t.reserve_lds_colour : t.reserve_lds;
+    uint32_t want = CM != 0 ? t.reserve_lds_colour : t.reserve_lds;
+    // A list of one attractor carries the loop of the list kernels: 7 workgroups per CU
+    // (0.741 ms at 100 M particles) rather than the 6 of the plain kernel (0.783 ms).
+    if (FORCE >= 2 && want == 26624u) want = 23040u;
     const uint32_t extra = want > used ? want - used : 0;
     if (t.nontemporal)
         hipLaunchKernelGGL((update_kernel<CM, FORCE, true>), dim3(grid), dim3(PSIM_UPDATE_BLOCK),
@@ -456,10 +511,12 @@ uint32_t update_grid(uint32_t n, const LaunchTuning &t)
 // Fewer resident waves keep the twelve read/write streams inside a narrower address
 // window, which HBM serves better, until too few bytes are in flight; single-wave
 // workgroups give the finest control, so the update kernel runs 64-thread workgroups and
-// reserves (never touches) 23040 B of LDS per workgroup: 7 of them fit a CU's 160 KiB.
+// reserves (never touches) LDS per workgroup: 23040 B lets 7 of them fit a CU's 160 KiB,
+// 26624 B lets 6.  (Those figures are for non-temporal global stores; the nt sc1 buffer
+// stores of st_stream() add 2-3 % at every occupancy and move the best point from 7 to 6.)
 // By size (64 threads): 1 M particles plain without cap 7.3 k (cap 6.2 k); 6.25-14 M plain
 // + cap 6.6-7.0 k (the state fits the 256 MiB Infinity Cache); from 20 M on
-// non-temporal + cap 6.4 k (plain + cap 5.9 k).
+// streaming + cap 6.6 k (plain + cap 5.9 k).
 //
 // Attractor lists add ~80 VALU instructions per particle and attractor, in long
 // divide/sqrt dependency chains that a few waves per SIMD cannot hide.  At 100 M
@@ -472,12 +529,16 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     t.max_blocks = 0;
     t.nontemporal = state_bytes > 400000000ull ? 1 : 0;
     const bool cap = state_bytes >= 96000000ull && n_attractors < 4;
-    // 7 workgroups per CU up to 250 M particles (6.47-6.50 k); at 500 M and 1 G particles
-    // 6 are better (6.42-6.44 k against 6.32-6.34 k).
-    t.reserve_lds = cap ? (state_bytes >= 9600000000ull ? 26624u : 23040u) : 0u;
-    // With the colour store as a thirteenth stream 6 workgroups per CU are better than 7:
-    // 6.25-6.34 k against 6.13-6.17 k GB/s of the 64 B stream (100 M particles).
-    t.reserve_lds_colour = cap ? (t.nontemporal ? 26624u : 23040u) : 0u;
+    // Streaming (nt loads, nt sc1 stores): 6 workgroups per CU, 6.64-6.68 k against 6.54-6.58 k
+    // for 7 at 100 M particles; the same holds with the colour store as a thirteenth stream
+    // and at 500 M / 1 G particles.  Cache-resident sizes (plain accesses): 7.
+    t.reserve_lds = cap ? (t.nontemporal ? 26624u : 23040u) : 0u;
+    t.reserve_lds_colour = t.reserve_lds;
+    // Streaming with a list of 2-4 attractors: 13 workgroups per CU (ms per step at 100 M
+    // particles, 2 / 4 attractors: 13 resident 0.752 / 0.766, 7 resident 0.854 / 1.05,
+    // 10 resident 0.769 / 0.889, uncapped 0.828 / 0.820).
+    if (t.nontemporal && n_attractors >= 2 && n_attractors <= 4)
+        t.reserve_lds = t.reserve_lds_colour = 11776u;
     return t;
 }
 
@@ -564,13 +625,24 @@ __global__ void __launch_bounds__(PSIM_BLOCK) gen_uniform_kernel(SoaPtrs s, uint
             pos[c] = unit_at(seed, c0 + c) * 100.0f - 50.0f;
             vel[c] = unit_at(seed, c0 + 3 + c) * 2.0f - 1.0f;
         }
-        st<NT>(s.px + i, pos[0]); st<NT>(s.py + i, pos[1]); st<NT>(s.pz + i, pos[2]);
-        st<NT>(s.vx + i, vel[0]); st<NT>(s.vy + i, vel[1]); st<NT>(s.vz + i, vel[2]);
         const f32x4 col = {(pos[0] / 50.0f + 1.0f) * 0.5f, (pos[1] / 50.0f + 1.0f) * 0.5f,
                            (pos[2] / 50.0f + 1.0f) * 0.5f, 1.0f};
-        st<NT>(reinterpret_cast<f32x4 *>(s.color) + i, col);
-        st<NT>(reinterpret_cast<f32x4 *>(s.initial_color) + i, col);
-        st<NT>(reinterpret_cast<f32x2 *>(s.padding) + i, f32x2{0.0f, 0.0f});
+        if constexpr (NT) {
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint64_t w0 = i - lane;                        // the wave's first particle
+            st_stream(s.px, w0, n, lane, pos[0]); st_stream(s.py, w0, n, lane, pos[1]);
+            st_stream(s.pz, w0, n, lane, pos[2]); st_stream(s.vx, w0, n, lane, vel[0]);
+            st_stream(s.vy, w0, n, lane, vel[1]); st_stream(s.vz, w0, n, lane, vel[2]);
+            st_stream(reinterpret_cast<f32x4 *>(s.color), w0, n, lane, col);
+            st_stream(reinterpret_cast<f32x4 *>(s.initial_color), w0, n, lane, col);
+            st_stream(reinterpret_cast<f32x2 *>(s.padding), w0, n, lane, f32x2{0.0f, 0.0f});
+        } else {
+            st<NT>(s.px + i, pos[0]); st<NT>(s.py + i, pos[1]); st<NT>(s.pz + i, pos[2]);
+            st<NT>(s.vx + i, vel[0]); st<NT>(s.vy + i, vel[1]); st<NT>(s.vz + i, vel[2]);
+            st<NT>(reinterpret_cast<f32x4 *>(s.color) + i, col);
+            st<NT>(reinterpret_cast<f32x4 *>(s.initial_color) + i, col);
+            st<NT>(reinterpret_cast<f32x2 *>(s.padding) + i, f32x2{0.0f, 0.0f});
+        }
     }
 }
 
@@ -626,7 +698,12 @@ __global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint3
     for (int k = 0; k < 4; ++k) {
         const uint32_t q = k * PSIM_BLOCK + t;                // quad index within the tile
         const uint32_t particle = q >> 2, field = q & 3u;
-        if (particle < live) st<NT>(aos + 4ull * base + q, tile[field][particle]);
+        if constexpr (NT) {
+            st_stream(aos, 4ull * base + (q & ~63u), 4ull * n, t & 63u,
+                      tile[field][particle < PSIM_BLOCK ? particle : 0]);
+        } else {
+            if (particle < live) st<NT>(aos + 4ull * base + q, tile[field][particle]);
+        }
     }
 }
 
@@ -649,11 +726,22 @@ __global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint3
     if (i < n) {
         const uint32_t dst = first + i;
         const f32x4 q0 = tile[0][t], q1 = tile[1][t];
-        st<NT>(s.px + dst, q0[0]); st<NT>(s.py + dst, q0[1]); st<NT>(s.pz + dst, q0[2]);
-        st<NT>(s.vx + dst, q1[0]); st<NT>(s.vy + dst, q1[1]); st<NT>(s.vz + dst, q1[2]);
-        st<NT>(reinterpret_cast<f32x2 *>(s.padding) + dst, f32x2{q0[3], q1[3]});
-        st<NT>(reinterpret_cast<f32x4 *>(s.color) + dst, tile[2][t]);
-        st<NT>(reinterpret_cast<f32x4 *>(s.initial_color) + dst, tile[3][t]);
+        if constexpr (NT) {
+            const uint32_t lane = t & 63u;
+            const uint64_t w0 = (uint64_t)dst - lane, end = (uint64_t)first + n;
+            st_stream(s.px, w0, end, lane, q0[0]); st_stream(s.py, w0, end, lane, q0[1]);
+            st_stream(s.pz, w0, end, lane, q0[2]); st_stream(s.vx, w0, end, lane, q1[0]);
+            st_stream(s.vy, w0, end, lane, q1[1]); st_stream(s.vz, w0, end, lane, q1[2]);
+            st_stream(reinterpret_cast<f32x2 *>(s.padding), w0, end, lane, f32x2{q0[3], q1[3]});
+            st_stream(reinterpret_cast<f32x4 *>(s.color), w0, end, lane, tile[2][t]);
+            st_stream(reinterpret_cast<f32x4 *>(s.initial_color), w0, end, lane, tile[3][t]);
+        } else {
+            st<NT>(s.px + dst, q0[0]); st<NT>(s.py + dst, q0[1]); st<NT>(s.pz + dst, q0[2]);
+            st<NT>(s.vx + dst, q1[0]); st<NT>(s.vy + dst, q1[1]); st<NT>(s.vz + dst, q1[2]);
+            st<NT>(reinterpret_cast<f32x2 *>(s.padding) + dst, f32x2{q0[3], q1[3]});
+            st<NT>(reinterpret_cast<f32x4 *>(s.color) + dst, tile[2][t]);
+            st<NT>(reinterpret_cast<f32x4 *>(s.initial_color) + dst, tile[3][t]);
+        }
     }
 }
 
