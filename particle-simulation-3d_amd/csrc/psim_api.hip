@@ -65,7 +65,7 @@ int env_int(const char *name, int dflt)
 // Optional overrides of the measured launch shape (experiments only): each is
 // read from the environment when a handle is created; -1 / unset = automatic.
 struct TuningOverrides {
-    int nontemporal = -1;   // PSIM_NT           0 | 1
+    int nontemporal = -1;   // PSIM_NT           0 plain | 1 streaming | 2 cache-resident accesses
     int reserve_lds = -1;   // PSIM_RESERVE_LDS  bytes of LDS reserved per workgroup
     int max_blocks = -1;    // PSIM_MAX_BLOCKS   grid cap (0 = one pass)
 };
@@ -82,7 +82,9 @@ TuningOverrides read_overrides()
 psim::LaunchTuning tuning_for(uint32_t n, uint32_t n_attractors, const TuningOverrides &o)
 {
     psim::LaunchTuning t = psim::choose_tuning(n, n_attractors);
-    if (o.nontemporal >= 0) t.nontemporal = o.nontemporal ? 1 : 0;
+    if (o.nontemporal >= 0)
+        t.access = o.nontemporal == 1 ? psim::PSIM_ACCESS_STREAM
+                 : o.nontemporal == 2 ? psim::PSIM_ACCESS_RESIDENT : psim::PSIM_ACCESS_PLAIN;
     if (o.reserve_lds >= 0) t.reserve_lds = t.reserve_lds_colour = (uint32_t)o.reserve_lds;
     if (o.max_blocks >= 0) t.max_blocks = (uint32_t)o.max_blocks;
     return t;

@@ -27,10 +27,17 @@ struct SoaPtrs {
     float *padding;        // 2 floats per particle (may be null for the update)
 };
 
+// How a kernel touches the particle state.
+enum : int {
+    PSIM_ACCESS_PLAIN = 0,      // global loads and stores (the state fits the L2s)
+    PSIM_ACCESS_RESIDENT = 1,   // plain loads, sc1 stores (the state fits the Infinity Cache)
+    PSIM_ACCESS_STREAM = 2      // nt loads, nt sc1 stores (the state is streamed from HBM)
+};
+
 // Launch shape of the update kernel.
 struct LaunchTuning {
     uint32_t max_blocks;   // 0 = one pass (grid covers every group), else grid-stride cap
-    int nontemporal;       // non-temporal loads/stores of the state arrays
+    int access;            // PSIM_ACCESS_*
     uint32_t reserve_lds;  // untouched dynamic LDS bytes per workgroup: caps workgroups per CU
     uint32_t reserve_lds_colour;   // the same for colour modes 1/2 (one more write stream)
 };

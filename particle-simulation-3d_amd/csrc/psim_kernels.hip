@@ -42,17 +42,23 @@ __device__ __forceinline__ void st(T *p, T v)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// Streaming store of one element (4, 8 or 16 bytes) per lane: the wave writes elements
-// first .. first+63 of `array`, lanes at or past element `limit` are dropped by the bounds
-// check of the buffer descriptor.  The store carries the cache-policy bits nt + sc1, which
-// the compiler does not emit for a plain or a non-temporal global store; measured on the
-// 100 M-particle update (GB/s of the 48 B stream, loads nt): stores nt 6.46 k, stores
-// sc0 sc1 6.51 k, stores nt sc1 6.57 k, plain stores 5.86 k.  `first` must be the same for
-// every lane of the wave.
+// Store of one element (4, 8 or 16 bytes) per lane with explicit cache-policy bits: the wave
+// writes elements first .. first+63 of `array`, lanes at or past element `limit` are dropped
+// by the bounds check of the buffer descriptor.  The compiler emits neither `sc1` alone nor
+// `nt sc1` for a plain or a non-temporal global store, and those are the fast ones.
+// Measured on the in-place update (GB/s of the 48 B stream):
+//   100 M particles (streaming, loads nt): stores plain 5.86 k | nt 6.46 k | sc0 sc1 6.51 k |
+//                                          nt sc1 6.57 k
+//   10 M / 6.25 M / 4 M (fit the Infinity Cache, loads plain): stores plain 7.03 / 6.83 /
+//                                          6.44 k | sc1 7.15 / 7.10 / 6.62 k | nt 6.3 k
+//   1 M (fits the L2s): stores plain 7.2 k | sc1 5.1 k
+// `first` must be the same for every lane of the wave.
 #define PSIM_BUFFER_WORD3 0x00020000   /* gfx9 family: raw buffer, 32-bit data format */
-#define PSIM_POLICY_NT_SC1 18          /* aux bits of the raw buffer intrinsics: 1 sc0, 2 nt, 16 sc1 */
-template <typename T>
-__device__ __forceinline__ void st_stream(T *array, uint64_t first, uint64_t limit,
+#define PSIM_POLICY_SC1 16             /* aux bits of the raw buffer intrinsics: 1 sc0, 2 nt, 16 sc1 */
+#define PSIM_POLICY_NT_SC1 18
+
+template <int POLICY, typename T>
+__device__ __forceinline__ void st_policy(T *array, uint64_t first, uint64_t limit,
                                           uint32_t lane, T v)
 {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "dword, dwordx2, dwordx4");
@@ -65,14 +71,30 @@ __device__ __forceinline__ void st_stream(T *array, uint64_t first, uint64_t lim
         __builtin_amdgcn_make_buffer_rsrc(array + f, 0, (int)bytes, PSIM_BUFFER_WORD3);
     const uint32_t off = lane * (uint32_t)sizeof(T);
     if constexpr (sizeof(T) == 16)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0,
-                                               PSIM_POLICY_NT_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, POLICY);
     else if constexpr (sizeof(T) == 8)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0,
-                                              PSIM_POLICY_NT_SC1);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, POLICY);
     else
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0,
-                                              PSIM_POLICY_NT_SC1);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, POLICY);
+}
+
+// The streaming form used by the kernels that only ever stream (generator, transposes).
+template <typename T>
+__device__ __forceinline__ void st_stream(T *array, uint64_t first, uint64_t limit,
+                                          uint32_t lane, T v)
+{
+    st_policy<PSIM_POLICY_NT_SC1>(array, first, limit, lane, v);
+}
+
+// One 16-byte quad per lane of the state arrays, by access mode.  `g0` is the wave's first
+// quad, `g` = g0 + lane the lane's own; lanes past `limit` must not call the plain form.
+template <int MODE>
+__device__ __forceinline__ void st_state(f32x4 *array, uint32_t g0, uint32_t limit, uint32_t lane,
+                                         f32x4 v)
+{
+    if constexpr (MODE == PSIM_ACCESS_STREAM) st_policy<PSIM_POLICY_NT_SC1>(array, g0, limit, lane, v);
+    else if constexpr (MODE == PSIM_ACCESS_RESIDENT) st_policy<PSIM_POLICY_SC1>(array, g0, limit, lane, v);
+    else array[g0 + lane] = v;
 }
 
 // ---- the per-particle step (src/simulation/cpu.rs:66-112) -------------------
@@ -178,9 +200,10 @@ struct KernargAttractors {
 //
 // CM    colour mode 0 (colour untouched, 48 B/particle), 1 or 2 (+16 B store).
 // FORCE see step().
-// NT    non-temporal loads and stores: a state larger than the 256 MiB Infinity
-//       Cache is streamed once per step, so keeping its lines cached only evicts
-//       useful ones; a cache-resident state is faster with plain accesses.
+// MODE  PSIM_ACCESS_*: a state larger than the 256 MiB Infinity Cache is streamed once per
+//       step, so keeping its lines cached only evicts useful ones (nt loads, nt sc1
+//       stores); a state that fits the Infinity Cache is fastest with plain loads and sc1
+//       stores; one that fits the L2s with plain accesses.
 //
 // A lane owns a group of 4 consecutive particles: one 16-byte access per array, so each
 // wave instruction covers 1 KiB of consecutive addresses.  Grid-stride over groups; a
@@ -200,7 +223,7 @@ struct KernargAttractors {
 // Stores the wave's 256 colour quads (`col` of every lane with `live`) to the colour array
 // of groups g0 .. g0+63 through the wave's LDS tile `t`, 1 KiB of consecutive bytes per
 // store instruction.  Must be reached by the whole wave.
-template <bool NT>
+template <int MODE>
 __device__ __forceinline__ void store_colours_transposed(f32x4 (*t)[PSIM_COLOUR_ROW],
                                                          f32x4 *col4, uint32_t g0, uint32_t lane,
                                                          bool live, uint32_t ngroups,
@@ -219,23 +242,28 @@ __device__ __forceinline__ void store_colours_transposed(f32x4 (*t)[PSIM_COLOUR_
     for (int k = 0; k < 4; ++k) {
         const uint32_t q = k * 64u + lane;                        // quad within the wave's 4 KiB
         const uint32_t src = q >> 2;                              // lane that computed it
-        if constexpr (NT) {
-            st_stream(col4, 4ull * g0 + 64u * k, 4ull * ngroups, lane, t[q & 3u][src]);
+        if constexpr (MODE == PSIM_ACCESS_STREAM) {
+            st_policy<PSIM_POLICY_NT_SC1>(col4, 4ull * g0 + 64u * k, 4ull * ngroups, lane,
+                                          t[q & 3u][src]);
+        } else if constexpr (MODE == PSIM_ACCESS_RESIDENT) {
+            st_policy<PSIM_POLICY_SC1>(col4, 4ull * g0 + 64u * k, 4ull * ngroups, lane,
+                                       t[q & 3u][src]);
         } else {
-            if (g0 + src < ngroups) st<NT>(col4 + 4ull * g0 + q, t[q & 3u][src]);
+            if (g0 + src < ngroups) col4[4ull * g0 + q] = t[q & 3u][src];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                              // a later call rewrites the tile
 }
 
-template <int CM, int FORCE, bool NT>
+template <int CM, int FORCE, int MODE>
 __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, uint32_t n,
                                                                   psim_sim_params p,
                                                                   const psim_attractor *attr_dev,
                                                                   uint32_t na,
                                                                   KernargAttractors ka)
 {
+    constexpr bool NT = MODE == PSIM_ACCESS_STREAM;          // non-temporal loads
     const psim_attractor *alist = nullptr;
     if constexpr (FORCE == 2) {
         // Stage the attractor list (<= 2 KiB) into LDS once per workgroup.
@@ -280,14 +308,9 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
                 x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
                 u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
             }
-            if constexpr (NT) {
-                st_stream(px4, g0, ngroups, lane, x); st_stream(py4, g0, ngroups, lane, y);
-                st_stream(pz4, g0, ngroups, lane, z); st_stream(vx4, g0, ngroups, lane, u);
-                st_stream(vy4, g0, ngroups, lane, v); st_stream(vz4, g0, ngroups, lane, w);
-            } else {
-                st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
-                st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
-            }
+            st_state<MODE>(px4, g0, ngroups, lane, x); st_state<MODE>(py4, g0, ngroups, lane, y);
+            st_state<MODE>(pz4, g0, ngroups, lane, z); st_state<MODE>(vx4, g0, ngroups, lane, u);
+            st_state<MODE>(vy4, g0, ngroups, lane, v); st_state<MODE>(vz4, g0, ngroups, lane, w);
             if constexpr (CM != 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -296,8 +319,8 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
         }
         if constexpr (CM != 0) {
             __shared__ f32x4 tile[PSIM_UPDATE_BLOCK / 64][4][PSIM_COLOUR_ROW];
-            store_colours_transposed<NT>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
-                                         col);
+            store_colours_transposed<MODE>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
+                                           col);
         }
     }
 
@@ -368,12 +391,13 @@ __device__ __forceinline__ void step_batch(float (&a)[N], float (&b)[N], float (
     }
 }
 
-template <bool NT>
+template <int MODE>
 __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs s, uint32_t n,
                                                                         BatchParams bp,
                                                                         uint32_t nsteps,
                                                                         int colour_step)
 {
+    constexpr bool NT = MODE == PSIM_ACCESS_STREAM;
     __shared__ f32x4 tile[PSIM_UPDATE_BLOCK / 64][4][PSIM_COLOUR_ROW];
     f32x4 *px4 = reinterpret_cast<f32x4 *>(s.px), *py4 = reinterpret_cast<f32x4 *>(s.py),
           *pz4 = reinterpret_cast<f32x4 *>(s.pz), *vx4 = reinterpret_cast<f32x4 *>(s.vx),
@@ -403,18 +427,13 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs
                 x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
                 u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
             }
-            if constexpr (NT) {
-                st_stream(px4, g0, ngroups, lane, x); st_stream(py4, g0, ngroups, lane, y);
-                st_stream(pz4, g0, ngroups, lane, z); st_stream(vx4, g0, ngroups, lane, u);
-                st_stream(vy4, g0, ngroups, lane, v); st_stream(vz4, g0, ngroups, lane, w);
-            } else {
-                st<NT>(px4 + g, x); st<NT>(py4 + g, y); st<NT>(pz4 + g, z);
-                st<NT>(vx4 + g, u); st<NT>(vy4 + g, v); st<NT>(vz4 + g, w);
-            }
+            st_state<MODE>(px4, g0, ngroups, lane, x); st_state<MODE>(py4, g0, ngroups, lane, y);
+            st_state<MODE>(pz4, g0, ngroups, lane, z); st_state<MODE>(vx4, g0, ngroups, lane, u);
+            st_state<MODE>(vy4, g0, ngroups, lane, v); st_state<MODE>(vz4, g0, ngroups, lane, w);
         }
         if (colour_step >= 0)                                     // uniform over the grid
-            store_colours_transposed<NT>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
-                                         col);
+            store_colours_transposed<MODE>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
+                                           col);
     }
 
     // Tail: particles 4*ngroups .. n-1.
@@ -443,12 +462,19 @@ hipError_t launch_update_batch(const SoaPtrs &s, uint32_t n, const psim_sim_para
     const uint32_t grid = update_grid(n, t);
     constexpr uint32_t used = (PSIM_UPDATE_BLOCK / 64) * 4 * PSIM_COLOUR_ROW * 16;
     const uint32_t extra = t.reserve_lds > used ? t.reserve_lds - used : 0;
-    if (t.nontemporal)
-        hipLaunchKernelGGL(update_batch_kernel<true>, dim3(grid), dim3(PSIM_UPDATE_BLOCK), extra,
-                           stream, s, n, bp, nsteps, colour_step);
-    else
-        hipLaunchKernelGGL(update_batch_kernel<false>, dim3(grid), dim3(PSIM_UPDATE_BLOCK), extra,
-                           stream, s, n, bp, nsteps, colour_step);
+    switch (t.access) {
+    case PSIM_ACCESS_STREAM:
+        hipLaunchKernelGGL(update_batch_kernel<PSIM_ACCESS_STREAM>, dim3(grid),
+                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, bp, nsteps, colour_step);
+        break;
+    case PSIM_ACCESS_RESIDENT:
+        hipLaunchKernelGGL(update_batch_kernel<PSIM_ACCESS_RESIDENT>, dim3(grid),
+                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, bp, nsteps, colour_step);
+        break;
+    default:
+        hipLaunchKernelGGL(update_batch_kernel<PSIM_ACCESS_PLAIN>, dim3(grid),
+                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, bp, nsteps, colour_step);
+    }
     return hipGetLastError();
 }
 
@@ -470,12 +496,19 @@ static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params 
     // (0.741 ms at 100 M particles) rather than the 6 of the plain kernel (0.783 ms).
     if (FORCE >= 2 && want == 26624u) want = 23040u;
     const uint32_t extra = want > used ? want - used : 0;
-    if (t.nontemporal)
-        hipLaunchKernelGGL((update_kernel<CM, FORCE, true>), dim3(grid), dim3(PSIM_UPDATE_BLOCK),
-                           extra, stream, s, n, p, attr_dev, na, ka);
-    else
-        hipLaunchKernelGGL((update_kernel<CM, FORCE, false>), dim3(grid), dim3(PSIM_UPDATE_BLOCK),
-                           extra, stream, s, n, p, attr_dev, na, ka);
+    switch (t.access) {
+    case PSIM_ACCESS_STREAM:
+        hipLaunchKernelGGL((update_kernel<CM, FORCE, PSIM_ACCESS_STREAM>), dim3(grid),
+                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, p, attr_dev, na, ka);
+        break;
+    case PSIM_ACCESS_RESIDENT:
+        hipLaunchKernelGGL((update_kernel<CM, FORCE, PSIM_ACCESS_RESIDENT>), dim3(grid),
+                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, p, attr_dev, na, ka);
+        break;
+    default:
+        hipLaunchKernelGGL((update_kernel<CM, FORCE, PSIM_ACCESS_PLAIN>), dim3(grid),
+                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, p, attr_dev, na, ka);
+    }
     return hipGetLastError();
 }
 
@@ -527,17 +560,26 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     const uint64_t state_bytes = 24ull * n;
     LaunchTuning t;
     t.max_blocks = 0;
-    t.nontemporal = state_bytes > 400000000ull ? 1 : 0;
+    // By state size (GB/s of the 48 B stream, best access mode of plain / resident / stream):
+    //   4 M particles 6.57 / 6.86 / -      6.25 M 6.92 / 7.06 / -     10 M 7.08 / 7.20 / 6.3
+    //   11 M 7.12 / 7.27 / 6.51            12.5 M 6.57 / 6.07 / 6.14  14 M 6.61 / 6.24 / 6.54
+    //   16 M 6.36 / 6.28 / 6.53            18 M 6.17 / 6.00 / 6.53    100 M 5.9 / - / 6.65
+    // i.e. sc1 stores while the state fits the 256 MiB Infinity Cache, plain accesses in the
+    // narrow band just above it, streaming from ~360 MB on.
+    const bool stream = state_bytes > 360000000ull;
+    const bool resident = state_bytes >= 96000000ull && state_bytes <= 268000000ull;
+    t.access = stream ? PSIM_ACCESS_STREAM : (resident ? PSIM_ACCESS_RESIDENT : PSIM_ACCESS_PLAIN);
     const bool cap = state_bytes >= 96000000ull && n_attractors < 4;
     // Streaming (nt loads, nt sc1 stores): 6 workgroups per CU, 6.64-6.68 k against 6.54-6.58 k
     // for 7 at 100 M particles; the same holds with the colour store as a thirteenth stream
-    // and at 500 M / 1 G particles.  Cache-resident sizes (plain accesses): 7.
-    t.reserve_lds = cap ? (t.nontemporal ? 26624u : 23040u) : 0u;
+    // and at 500 M / 1 G particles.  Resident: 6 and 7 are equal (4-11 M particles).  Plain
+    // band: 7 (6.57-6.61 k against 6.28-6.48 k for 6).
+    t.reserve_lds = cap ? ((stream || resident) ? 26624u : 23040u) : 0u;
     t.reserve_lds_colour = t.reserve_lds;
     // Streaming with a list of 2-4 attractors: 13 workgroups per CU (ms per step at 100 M
     // particles, 2 / 4 attractors: 13 resident 0.752 / 0.766, 7 resident 0.854 / 1.05,
     // 10 resident 0.769 / 0.889, uncapped 0.828 / 0.820).
-    if (t.nontemporal && n_attractors >= 2 && n_attractors <= 4)
+    if (state_bytes >= 96000000ull && n_attractors >= 2 && n_attractors <= 4)
         t.reserve_lds = t.reserve_lds_colour = 11776u;
     return t;
 }

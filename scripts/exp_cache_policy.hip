@@ -152,7 +152,7 @@ int main(int argc, char **argv)
                            c < 3 ? 100.0f : 2.0f, c < 3 ? -50.0f : -1.0f, (uint32_t)c);
     }
     printf("== %zu particles, single-wave workgroups, 7 per CU\n", n);
-    const int lds = 23040;
+    const int lds = argc > 2 ? atoi(argv[2]) : 23040;
     run_stores<0>(s, arr, ngroups, lds);
     run_stores<1>(s, arr, ngroups, lds);
     run_stores<2>(s, arr, ngroups, lds);
