@@ -44,19 +44,19 @@ def main():
 
     # (kernel-name fragment as rocprofv3 prints it, what it is, algorithmic bytes, call)
     ops = [
-        ("update_kernel<0, 1, true>", "update, single attractor r=10, colour 0", 48 * n,
+        ("update_kernel<0, 1, 2>", "update, single attractor r=10, colour 0", 48 * n,
          lambda: sim.update(P())),
-        ("update_kernel<0, 0, true>", "update, no attractor", 48 * n,
+        ("update_kernel<0, 0, 2>", "update, no attractor", 48 * n,
          lambda: sim.update(P(is_mouse_dragging=0))),
-        ("update_kernel<1, 1, true>", "update, r=50, colour mode 1", 64 * n,
+        ("update_kernel<1, 1, 2>", "update, r=50, colour mode 1", 64 * n,
          lambda: sim.update(P(mouse_radius=50.0, color_mode=1))),
-        ("update_kernel<2, 1, true>", "update, r=50, colour mode 2", 64 * n,
+        ("update_kernel<2, 1, 2>", "update, r=50, colour mode 2", 64 * n,
          lambda: sim.update(P(mouse_radius=50.0, color_mode=2))),
-        ("update_kernel<0, 3, true>", "update, 8 attractors in kernel arguments", 48 * n,
+        ("update_kernel<0, 3, 2>", "update, 8 attractors in kernel arguments", 48 * n,
          lambda: sim.update_multi(P(), a8)),
-        ("update_kernel<0, 2, true>", "update, 8 attractors staged in LDS", 48 * n,
+        ("update_kernel<0, 2, 2>", "update, 8 attractors staged in LDS", 48 * n,
          lambda: sim.update_multi_device(P(), attr_buf, 8)),
-        ("update_batch_kernel<true>", "16 fused steps", 48 * n,
+        ("update_batch_kernel<2>", "16 fused steps", 48 * n,
          lambda: sim.update_batch(batch)),
         ("export_aos_kernel<true>", "SoA -> 64-byte records", 128 * n,
          lambda: sim.export_aos_device(aos_buf)),
