@@ -147,7 +147,12 @@ int main(int argc, char **argv)
     CHECK(hipStreamCreate(&s));
     Arrays arr;
     for (int c = 0; c < 6; ++c) {
-        CHECK(hipMalloc((void **)&arr.a[c], (size_t)ngroups * 16));
+        // third argument: 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained
+        const int kind = argc > 3 ? atoi(argv[3]) : 0;
+        if (kind == 0) CHECK(hipMalloc((void **)&arr.a[c], (size_t)ngroups * 16));
+        else CHECK(hipExtMallocWithFlags((void **)&arr.a[c], (size_t)ngroups * 16,
+                                         kind == 1 ? hipDeviceMallocUncached
+                                                   : hipDeviceMallocFinegrained));
         hipLaunchKernelGGL(fill_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, arr.a[c], n,
                            c < 3 ? 100.0f : 2.0f, c < 3 ? -50.0f : -1.0f, (uint32_t)c);
     }
