@@ -46,6 +46,35 @@ __device__ __forceinline__ void step1(float &px, float &py, float &pz, float &vx
     vx = vx * damping; vy = vy * damping; vz = vz * damping;
 }
 
+// XCD-contiguous variant: workgroups are dealt round-robin to the 8 XCDs, so workgroup b runs on
+// XCD b % 8; here XCD k sweeps the k-th eighth of every array instead of every 8th KiB.
+template <int LD, int ST>
+__global__ void update_xcd(Arrays s, uint32_t ngroups, uint32_t bytes)
+{
+    const uint32_t per = (gridDim.x + 7u) / 8u;
+    const uint32_t block = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const uint32_t g = block * blockDim.x + threadIdx.x;
+    if (block >= gridDim.x || g >= ngroups) return;
+    const uint32_t off = g * 16u;
+    f32x4 r[6];
+    __amdgpu_buffer_rsrc_t rs[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        rs[c] = __builtin_amdgcn_make_buffer_rsrc(s.a[c], 0, (int)bytes, 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs[c], off, 0, LD);
+        r[c] = __builtin_bit_cast(f32x4, v);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = r[0][j], y = r[1][j], z = r[2][j], u = r[3][j], v = r[4][j], w = r[5][j];
+        step1(x, y, z, u, v, w);
+        r[0][j] = x; r[1][j] = y; r[2][j] = z; r[3][j] = u; r[4][j] = v; r[5][j] = w;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[c]), rs[c], off, 0, ST);
+}
+
 template <int LD, int ST>
 __global__ void update(Arrays s, uint32_t ngroups, uint32_t bytes)
 {
@@ -156,8 +185,35 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(fill_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, arr.a[c], n,
                            c < 3 ? 100.0f : 2.0f, c < 3 ? -50.0f : -1.0f, (uint32_t)c);
     }
-    printf("== %zu particles, single-wave workgroups, 7 per CU\n", n);
     const int lds = argc > 2 ? atoi(argv[2]) : 23040;
+    if (argc > 4) {            // fourth argument: compare the workgroup -> address mappings only
+        const uint32_t grid = (ngroups + 63) / 64;
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        for (int variant = 0; variant < 2; ++variant)
+            for (int round = 0; round < 4; ++round) {
+                CHECK(hipEventRecord(e0, s));
+                for (int i = 0; i < 20; ++i) {
+                    if (variant == 0)
+                        hipLaunchKernelGGL((update<2, 18>), dim3(grid), dim3(64), lds, s, arr, ngroups,
+                                           ngroups * 16u);
+                    else
+                        hipLaunchKernelGGL((update_xcd<2, 18>), dim3(grid), dim3(64), lds, s, arr,
+                                           ngroups, ngroups * 16u);
+                }
+                CHECK(hipEventRecord(e1, s));
+                CHECK(hipEventSynchronize(e1));
+                float t;
+                CHECK(hipEventElapsedTime(&t, e0, e1));
+                printf("%s lds %5d: %.4f ms  %7.1f GB/s\n",
+                       variant ? "XCD-contiguous eighths  " : "round-robin (index order)", lds, t / 20,
+                       192.0 * ngroups / (t / 20) / 1e6);
+            }
+        CHECK(hipGetLastError());
+        return 0;
+    }
+    printf("== %zu particles, single-wave workgroups, 7 per CU\n", n);
     run_stores<0>(s, arr, ngroups, lds);
     run_stores<1>(s, arr, ngroups, lds);
     run_stores<2>(s, arr, ngroups, lds);
