@@ -41,7 +41,13 @@ __device__ __forceinline__ f32x4 ld(const f32x4 *p)
 template <bool NT>
 __device__ __forceinline__ void st(f32x4 *p, f32x4 v)
 {
+#ifdef EXP_NT_SC1
+    // build with -DEXP_NT_SC1: non-temporal stores carry nt + sc1 (every kernel here stores
+    // last, so the compiler's wait counting is not disturbed by the hand-written store)
+    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
+#else
     if constexpr (NT) __builtin_nontemporal_store(v, p);
+#endif
     else *p = v;
 }
 
