@@ -300,6 +300,22 @@ int psim_device(const psim_handle *h);
 int psim_timer_start(psim_handle *h);
 int psim_timer_stop(psim_handle *h, float *elapsed_ms);
 
+/* The launch shape the library picks for an update of `count` particles with
+ * `n_attractors` attractors (1 for psim_update).  The reference hard-codes one shape,
+ * `dispatch_workgroups(count.div_ceil(256))` of 256-thread workgroups
+ * (src/simulation/compute.rs:142-143, src/shaders/compute.wgsl:31); here it depends on
+ * whether the state fits the L2s, the Infinity Cache or neither.  Needs no device. */
+typedef struct psim_launch_shape_info {
+    int      access;              /* 0 plain accesses, 1 plain loads + sc1 stores
+                                     (cache-resident), 2 nt loads + nt sc1 stores (streaming) */
+    uint32_t workgroup_size;      /* threads per workgroup */
+    uint32_t workgroups;          /* grid size */
+    uint32_t reserve_lds;         /* LDS bytes reserved per workgroup to cap residency, colour mode 0 */
+    uint32_t reserve_lds_colour;  /* the same for colour modes 1 / 2 */
+    uint32_t resident_per_cu;     /* workgroups a CU's 160 KiB of LDS then holds (0 = not capped) */
+} psim_launch_shape_info;
+int psim_launch_shape(uint32_t count, uint32_t n_attractors, psim_launch_shape_info *out);
+
 /* ---- errors --------------------------------------------------------------- */
 
 /* Text of the most recent failure on the calling thread ("" if none). */

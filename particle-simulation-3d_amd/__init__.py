@@ -105,8 +105,19 @@ MAX_ATTRACTORS = 64
 MAX_HOST_ATTRACTORS = 8
 
 # Every symbol include/psim.h declares: name -> (restype, argtypes).
+class LaunchShapeInfo(ctypes.Structure):
+    """`psim_launch_shape_info`: the launch shape picked for a particle count."""
+
+    _fields_ = [("access", c_int), ("workgroup_size", c_uint32), ("workgroups", c_uint32),
+                ("reserve_lds", c_uint32), ("reserve_lds_colour", c_uint32),
+                ("resident_per_cu", c_uint32)]
+
+
+ACCESS_PLAIN, ACCESS_RESIDENT, ACCESS_STREAM = 0, 1, 2
+
 _P = c_void_p
 ABI = {
+    "psim_launch_shape": (c_int, [c_uint32, c_uint32, POINTER(LaunchShapeInfo)]),
     "psim_create": (c_int, [POINTER(_P), c_uint32, c_int, c_int]),
     "psim_create_shard": (c_int, [POINTER(_P), c_uint32, c_uint64, c_uint64, c_int, c_int]),
     "psim_destroy": (None, [_P]),
@@ -422,6 +433,13 @@ def pinned_empty(n, dtype=PARTICLE_DTYPE):
     raw = (ctypes.c_char * max(nbytes, 1)).from_address(block.ptr)
     raw._owner = block                       # the numpy array keeps `raw`, `raw` keeps the block
     return np.frombuffer(raw, dtype=np.uint8, count=nbytes).view(dtype)
+
+
+def launch_shape(count, n_attractors=1):
+    """The launch shape the library picks for `count` particles (no device needed)."""
+    info = LaunchShapeInfo()
+    _check(load_library().psim_launch_shape(count, n_attractors, byref(info)))
+    return {name: getattr(info, name) for name, _ in LaunchShapeInfo._fields_}
 
 
 def version():

@@ -764,6 +764,22 @@ PSIM_API int psim_timer_stop(psim_handle *h, float *elapsed_ms)
 
 // ---- errors -------------------------------------------------------------------
 
+PSIM_API int psim_launch_shape(uint32_t count, uint32_t n_attractors, psim_launch_shape_info *out)
+{
+    if (!out) return fail(PSIM_ERR_INVALID, "null output");
+    if (n_attractors > PSIM_MAX_ATTRACTORS)
+        return fail(PSIM_ERR_INVALID, "%u attractors exceed the maximum of %u", n_attractors,
+                    PSIM_MAX_ATTRACTORS);
+    const psim::LaunchTuning t = psim::choose_tuning(count, n_attractors);
+    out->access = t.access;
+    out->workgroup_size = PSIM_UPDATE_BLOCK;
+    out->workgroups = psim::update_grid(count, t);
+    out->reserve_lds = t.reserve_lds;
+    out->reserve_lds_colour = t.reserve_lds_colour;
+    out->resident_per_cu = t.reserve_lds ? 163840u / t.reserve_lds : 0u;
+    return PSIM_OK;
+}
+
 PSIM_API const char *psim_last_error(void) { return g_error; }
 
 PSIM_API const char *psim_version(void) { return "psim-hip 0.1 (gfx950)"; }
