@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--workload", choices=["single", "multi"], default="single",
                     help="single: one attractor, no communication (headline); "
                          "multi: one moving attractor per rank, all-gathered every step")
+    ap.add_argument("--lookahead", type=int, default=1,
+                    help="multi workload: steps of attractor state exchanged per all-gather "
+                         "(1 = one collective per step)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000,
                     help="particles of the same workload stepped by the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -142,7 +145,8 @@ def main():
 
     if args.workload == "multi":
         par = importlib.import_module("particle-simulation-3d_amd.parallel")
-        runner = par.MultiAttractorRunner(n, rank, world, local_rank, params)
+        runner = par.MultiAttractorRunner(n, rank, world, local_rank, params,
+                                          lookahead=args.lookahead)
         step, finish, sim = runner.step, runner.finish, runner.sim
     else:
         sim = psim.HipParticleSimulation.new_shard(n, rank * n, world * n, psim.GEN_UNIFORM,
@@ -199,7 +203,10 @@ def main():
                 "total_particles": world * n,
                 "sharding": f"contiguous index ranges x{world}, no data-path collective"
                             if args.workload == "single" else
-                            f"contiguous index ranges x{world}, all-gather of 32 B per rank per step",
+                            (f"contiguous index ranges x{world}, all-gather of 32 B per rank per step"
+                             if args.lookahead == 1 else
+                             f"contiguous index ranges x{world}, all-gather of {args.lookahead} x 32 B "
+                             f"per rank every {args.lookahead} steps"),
             },
             "roofline": {
                 "bound": "hbm",

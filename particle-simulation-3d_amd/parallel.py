@@ -106,10 +106,17 @@ class MultiAttractorRunner:
       compute stream : wait for that all-gather; multi-attractor update kernel reading
                        recv[t%2] (staged into LDS by every workgroup)
     so the all-gather of step t+1 overlaps the kernel of step t.
+
+    `lookahead` = K > 1: the attractor paths are known ahead (closed form), so one
+    collective carries K steps of every rank's attractor (K x 32 B per rank, staged through
+    page-locked memory), a small device copy reorders the gathered [rank][step] records
+    into one list per step, and the K update kernels that follow need no host work besides
+    their launches.  The particles come out identical; only the number of collectives
+    changes (one per K steps).
     """
 
     def __init__(self, particles_per_rank, rank, world, local_rank, params, group=None,
-                 force=5.0, radius=10.0):
+                 force=5.0, radius=10.0, lookahead=1):
         import torch
         import torch.distributed as dist
         self._torch, self._dist, self._group = torch, dist, group
@@ -141,6 +148,20 @@ class MultiAttractorRunner:
         torch.cuda.set_stream(self.comm)
         self._path = None          # own attractor records for steps [_path_first, +len)
         self._path_first = 0
+        self.lookahead = int(lookahead)
+        if self.lookahead < 1:
+            raise ValueError("lookahead must be >= 1")
+        if self.lookahead > 1:
+            k = self.lookahead
+            self.host = [torch.empty(k * ATTRACTOR_FLOATS, dtype=torch.float32).pin_memory()
+                         for _ in range(2)]
+            self.send = [torch.zeros(k * ATTRACTOR_FLOATS, dtype=torch.float32, device=dev)
+                         for _ in range(2)]
+            self.recv = [torch.zeros(world * k * ATTRACTOR_FLOATS, dtype=torch.float32, device=dev)
+                         for _ in range(2)]
+            self.lists = [torch.zeros(k * world * ATTRACTOR_FLOATS, dtype=torch.float32,
+                                      device=dev) for _ in range(2)]
+            self.lists_ptr = [t.data_ptr() for t in self.lists]
 
     def _own_attractor(self, t):
         """This rank's attractor at step t, from a table refilled 256 steps at a time."""
@@ -149,7 +170,36 @@ class MultiAttractorRunner:
             self._path = attractor_table(t, 256, self.rank, self.force, self.radius)
         return self._path[t - self._path_first:t - self._path_first + 1]
 
+    def _gather_ahead(self, cycle):
+        """Exchanges the attractors of steps cycle*K .. cycle*K + K-1 in one collective."""
+        k, w, b = self.lookahead, self.world, cycle % 2
+        if cycle >= 2:
+            self.gathered[b].synchronize()     # host: the staging of cycle-2 has been consumed
+            self.comm.wait_event(self.kernel_done[b])      # device: its lists have been read
+        table = attractor_table(cycle * k, k, self.rank, self.force, self.radius)
+        self.host[b].numpy()[:] = table.view(np.float32).reshape(-1)
+        self.send[b].copy_(self.host[b], non_blocking=True)          # on the comm stream
+        self._dist.all_gather_into_tensor(self.recv[b], self.send[b], group=self._group)
+        self.lists[b].view(k, w, ATTRACTOR_FLOATS).copy_(
+            self.recv[b].view(w, k, ATTRACTOR_FLOATS).transpose(0, 1))
+        self.gathered[b].record(self.comm)
+        self.compute.wait_event(self.gathered[b])
+
+    def _step_ahead(self):
+        k = self.lookahead
+        cycle, s = divmod(self.t, k)
+        if s == 0:
+            self._gather_ahead(cycle)
+        b = cycle % 2
+        self.sim.update_multi_device(
+            self.params, self.lists_ptr[b] + s * self.world * ATTRACTOR_DTYPE.itemsize, self.world)
+        if s == k - 1:
+            self.kernel_done[b].record(self.compute)
+        self.t += 1
+
     def step(self):
+        if self.lookahead > 1:
+            return self._step_ahead()
         b = self.t % 2
         if self.t >= 2:                        # the kernel of step t-2 read recv[b]
             self.comm.wait_event(self.kernel_done[b])

@@ -20,11 +20,14 @@ def free_port():
         return s.getsockname()[1]
 
 
-def test_multi_attractor_runner_single_rank(tmp_path):
+@pytest.mark.parametrize("lookahead", [1, 5])
+def test_multi_attractor_runner_single_rank(tmp_path, lookahead):
+    """lookahead 1: one all-gather per step; 5: one per 5 steps (12 steps = 2 full cycles
+    and a partial one).  Both must equal the oracle with all attractors applied in order."""
     out = tmp_path / "result.txt"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-u", WORKER, "300007", "12", str(out)], env=env,
-                       capture_output=True, text=True, timeout=170)
+    r = subprocess.run([sys.executable, "-u", WORKER, "300007", "12", str(out), str(lookahead)],
+                       env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert out.read_text().startswith("OK world=1")
