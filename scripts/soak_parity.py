@@ -41,13 +41,81 @@ def stream(steps):
     return out
 
 
+def mixed_soak(n, steps, every):
+    """Every feature of the path in one run, on the reference's 64-byte records: colour modes
+    cycling, attractor lists of 3 (host list) every seventh step, fused batches on alternate
+    chunks, compute-shader colour semantics switched on for the second half."""
+    lib = T.load_oracle()
+    threads = int(lib.psim_oracle_max_threads())
+    params = stream(steps)
+    for i, p in enumerate(params):
+        p.color_mode = (0, 1, 2, 0, 0, 1, 7)[(i // 5) % 7]
+    rng = np.random.default_rng(3)
+    lst = np.zeros(3, dtype=psim.ATTRACTOR_DTYPE)
+    lst["position"] = rng.uniform(-40, 40, size=(3, 3)).astype(np.float32)
+    lst["force"], lst["radius"], lst["active"] = 20.0, 15.0, 1
+
+    sim = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
+    ref = T.oracle_gen_uniform_aos(0, n)
+    ref_ptr = T._ptr(ref)
+    lst_ptr = T._ptr(lst)
+    print(f"mixed soak: particles={n} steps={steps} oracle threads={threads}", flush=True)
+    reset = False
+    dirty = False                                   # colours differ from the initial colours
+    done = 0
+    while done < steps:
+        m = min(every, steps - done)
+        if done >= steps // 2 and not reset:
+            sim.set_color_semantics(psim.COLOR_RESET)
+            reset = True
+        chunk = list(range(done, done + m))
+        fused = (done // every) % 2 == 1
+        pending = []
+        for i in chunk:
+            multi = i % 7 == 6
+            if fused and not multi:
+                pending.append(params[i])
+            else:
+                if pending:
+                    sim.update_batch(pending)
+                    pending = []
+                if multi:
+                    sim.update_multi(params[i], lst)
+                else:
+                    sim.update(params[i])
+            lib.psim_oracle_update_aos(ref_ptr, n, ctypes.byref(params[i]),
+                                       lst_ptr if multi else None, 3 if multi else 0, threads)
+            if params[i].color_mode in (1, 2):
+                dirty = True
+            elif reset and dirty:                   # the shader's rule, applied to the oracle's state
+                ref["color"] = ref["initial_color"]
+                dirty = False
+        if pending:
+            sim.update_batch(pending)
+        done += m
+        want = T.oracle_checksum_soa(T.aos_to_soa(ref))
+        ok = sim.checksum() == want
+        print(f"step {done:5d}: checksums {'equal' if ok else 'DIFFER'}"
+              f"{' (colour reset semantics)' if reset else ''}", flush=True)
+        if not ok:
+            sys.exit(1)
+    got = sim.download_aos()
+    T.assert_particles_equal(got, ref, "mixed soak, final records")
+    print(f"final records: bit-identical over {n} particles x 64 bytes "
+          f"(position, velocity, colour, initial colour, paddings)", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--particles", type=int, default=100_000_000)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--every", type=int, default=50)
+    ap.add_argument("--mix", action="store_true",
+                    help="colour modes, attractor lists, fused batches and colour semantics mixed")
     args = ap.parse_args()
     n = args.particles
+    if args.mix:
+        return mixed_soak(n, args.steps, args.every)
     lib = T.load_oracle()
     threads = int(lib.psim_oracle_max_threads())
     params = stream(args.steps)
