@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "psim_kernels.h"
+#include "psim_threshold.h"
 
 #pragma clang fp contract(off)
 
@@ -105,14 +106,17 @@ __device__ __forceinline__ float length3(float x, float y, float z)
     return sqrtf((x * x + y * y) + z * z);
 }
 
-// Force law of one attractor, cpu.rs:76-83.  `two_r` is radius * 2.0.
+// Force law of one attractor, cpu.rs:76-83.  `two_r` is radius * 2.0, `thr` =
+// psim_in_range_threshold(two_r): `d2 < thr` is exactly the reference's `dist < two_r`
+// (psim_threshold.h).
 __device__ __forceinline__ void attract(float &vx, float &vy, float &vz, float px, float py,
                                         float pz, float ax, float ay, float az, float aforce,
-                                        float two_r, float dt)
+                                        float two_r, float thr, float dt)
 {
     const float dx = ax - px, dy = ay - py, dz = az - pz;    // cpu.rs:76
-    const float dist = length3(dx, dy, dz);                  // cpu.rs:77
-    if (dist < two_r) {                                      // cpu.rs:79
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (d2 < thr) {                                          // cpu.rs:79, see above
+        const float dist = sqrtf(d2);                        // cpu.rs:77
         const float t = 1.0f - dist / two_r;
         const float ff = (t * t) * 2.0f;                     // cpu.rs:80 powi(2) * 2.0
         const float inv = 1.0f / dist;                       // normalize = dir * (1/len)
@@ -142,21 +146,25 @@ __device__ __forceinline__ void step(float (&px)[N], float (&py)[N], float (&pz)
     const float gdt = p.gravity * dt;
 #pragma unroll
     for (int j = 0; j < N; ++j) vy[j] = vy[j] - gdt;         // cpu.rs:72
+    // The in-range threshold of each attractor rides in a padding word of the kernel's own
+    // copy of the record (SimParams::_padding2, psim_attractor::_pad[0]); see with_threshold().
     if constexpr (FORCE == 1) {
         const float two_r = p.mouse_radius * 2.0f;
+        const float thr = __uint_as_float(p._padding2);
 #pragma unroll
         for (int j = 0; j < N; ++j)
             attract(vx[j], vy[j], vz[j], px[j], py[j], pz[j], p.mouse_position[0],
-                    p.mouse_position[1], p.mouse_position[2], p.mouse_force, two_r, dt);
+                    p.mouse_position[1], p.mouse_position[2], p.mouse_force, two_r, thr, dt);
     } else if constexpr (FORCE >= 2) {
         for (uint32_t a = 0; a < na; ++a) {
             const psim_attractor at = alist[a];
             if (at.active > 0) {
                 const float two_r = at.radius * 2.0f;
+                const float thr = __uint_as_float(at._pad[0]);
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                     attract(vx[j], vy[j], vz[j], px[j], py[j], pz[j], at.position[0],
-                            at.position[1], at.position[2], at.force, two_r, dt);
+                            at.position[1], at.position[2], at.force, two_r, thr, dt);
             }
         }
     }
@@ -272,6 +280,11 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
         for (uint32_t w = threadIdx.x; w < words; w += PSIM_UPDATE_BLOCK)
             reinterpret_cast<uint32_t *>(lds_attr)[w] =
                 reinterpret_cast<const uint32_t *>(attr_dev)[w];
+        __syncthreads();
+        static_assert(PSIM_MAX_ATTRACTORS <= PSIM_UPDATE_BLOCK, "one lane per attractor");
+        if (threadIdx.x < na)                                 // one lane per attractor
+            lds_attr[threadIdx.x]._pad[0] =
+                __float_as_uint(psim_in_range_threshold(lds_attr[threadIdx.x].radius * 2.0f));
         __syncthreads();
         alist = lds_attr;
     } else if constexpr (FORCE == 3) {
@@ -456,6 +469,10 @@ hipError_t launch_update_batch(const SoaPtrs &s, uint32_t n, const psim_sim_para
     BatchParams bp;
     memset(&bp, 0, sizeof(bp));
     memcpy(bp.p, params, nsteps * sizeof(psim_sim_params));
+    for (uint32_t k = 0; k < nsteps; ++k) {                  // see step(): threshold per step
+        const float thr = psim_in_range_threshold(params[k].mouse_radius * 2.0f);
+        memcpy(&bp.p[k]._padding2, &thr, sizeof(thr));
+    }
     int colour_step = -1;
     for (uint32_t k = 0; k < nsteps; ++k)
         if (params[k].color_mode == 1 || params[k].color_mode == 2) colour_step = (int)k;
@@ -479,6 +496,24 @@ hipError_t launch_update_batch(const SoaPtrs &s, uint32_t n, const psim_sim_para
 }
 
 // ---- launch dispatch -------------------------------------------------------
+
+// The kernels' own copy of a SimParams / attractor record carries the in-range threshold of
+// its attractor in a padding word (the caller's records are never modified).
+static psim_sim_params with_threshold(const psim_sim_params &p)
+{
+    psim_sim_params q = p;
+    const float thr = psim_in_range_threshold(p.mouse_radius * 2.0f);
+    memcpy(&q._padding2, &thr, sizeof(thr));
+    return q;
+}
+
+static psim_attractor with_threshold(const psim_attractor &a)
+{
+    psim_attractor q = a;
+    const float thr = psim_in_range_threshold(a.radius * 2.0f);
+    memcpy(&q._pad[0], &thr, sizeof(thr));
+    return q;
+}
 
 template <int CM, int FORCE>
 static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
@@ -584,14 +619,16 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     return t;
 }
 
-hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &p, int force,
+hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &params, int force,
                          const psim_attractor *attr_dev, const psim_attractor *attr_host,
                          uint32_t na, const LaunchTuning &t, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+    const psim_sim_params p = with_threshold(params);
     KernargAttractors ka;
     memset(&ka, 0, sizeof(ka));
-    if (force == 3) memcpy(ka.a, attr_host, na * sizeof(psim_attractor));
+    if (force == 3)
+        for (uint32_t a = 0; a < na; ++a) ka.a[a] = with_threshold(attr_host[a]);
     const uint32_t grid = update_grid(n, t);
     switch (force) {
     case 0: return launch_cm<0>(s, n, p, nullptr, 0, ka, t, grid, stream);
@@ -601,10 +638,11 @@ hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
     }
 }
 
-hipError_t launch_update_scalar(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
+hipError_t launch_update_scalar(const SoaPtrs &s, uint32_t n, const psim_sim_params &params,
                                 uint32_t max_blocks, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+    const psim_sim_params p = with_threshold(params);
     uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
     if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
     const bool drag = p.is_mouse_dragging > 0;

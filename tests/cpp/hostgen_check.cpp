@@ -10,7 +10,10 @@
 #include <string>
 #include <vector>
 
+#include <cmath>
+
 #include "psim_hostgen.h"
+#include "psim_threshold.h"
 
 using psim_hostgen::Xoshiro256pp;
 
@@ -63,6 +66,40 @@ int main(int argc, char **argv)
         a.jump(987654321ull);
         b.jump(123456789ull + 987654321ull);
         if (std::memcmp(a.s, b.s, sizeof(a.s)) != 0) return fail("jump is not additive");
+    }
+
+    // psim_in_range_threshold: `d2 < T` must equal `sqrtf(d2) < two_r` for every d2, checked
+    // on the floats around T, around two_r^2, and at the special values, for many radii
+    {
+        Xoshiro256pp g(11);
+        std::vector<float> radii = {0.0f, -1.0f, 1e-30f, 1e-23f, 1e-20f, 3e-19f, 0.5f, 1.0f, 2.0f, 20.0f,
+                                    100.0f, 1.8e19f, 1.9e19f, 3e38f, INFINITY, NAN};
+        for (int i = 0; i < 20000; ++i) {
+            union { uint32_t u; float f; } r;
+            r.u = (uint32_t)(g.next() >> 33);               // any positive bit pattern
+            radii.push_back(r.f);
+            radii.push_back(g.next_f32() * 100.0f);         // the slider range, doubled
+        }
+        for (float two_r : radii) {
+            const float T = psim_in_range_threshold(two_r);
+            std::vector<float> probes = {0.0f, 1.4e-45f, 1.0f, 3.4028235e38f, INFINITY, NAN};
+            for (float centre : {T, two_r * two_r}) {
+                union { float f; uint32_t u; } b;
+                b.f = centre;
+                if (centre == centre && centre > 0.0f && centre < INFINITY)
+                    for (int d = -3; d <= 3; ++d) {
+                        if ((int64_t)b.u + d < 0) continue;
+                        union { float f; uint32_t u; } p;
+                        p.u = (uint32_t)((int64_t)b.u + d);
+                        probes.push_back(p.f);
+                    }
+            }
+            for (float d2 : probes)
+                if ((d2 < T) != (sqrtf(d2) < two_r)) {
+                    std::fprintf(stderr, "two_r %a T %a d2 %a\n", two_r, T, d2);
+                    return fail("d2 < T differs from sqrtf(d2) < two_r");
+                }
+        }
     }
 
     // slices of both states: one call over the range == many calls over its pieces
