@@ -472,7 +472,15 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
                      aligned16(vy) && aligned16(vz) && (!colours || aligned16(color));
     if (vec) {
         static const TuningOverrides overrides = read_overrides();   // read once per process
-        const psim::LaunchTuning t = tuning_for(count, 1, overrides);
+        psim::LaunchTuning t = tuning_for(count, 1, overrides);
+        // The sc1 / nt sc1 stores write partial 128-byte lines through to memory; arrays
+        // that are 16-byte but not line-aligned are faster with plain accesses (100 M
+        // particles, arrays 16 bytes off a line: 5.99 k GB/s plain against 5.14 k).
+        const uintptr_t any = reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(py) |
+                              reinterpret_cast<uintptr_t>(pz) | reinterpret_cast<uintptr_t>(vx) |
+                              reinterpret_cast<uintptr_t>(vy) | reinterpret_cast<uintptr_t>(vz) |
+                              (colours ? reinterpret_cast<uintptr_t>(color) : 0);
+        if ((any & 127u) != 0 && overrides.nontemporal < 0) t.access = psim::PSIM_ACCESS_PLAIN;
         HIP_TRY(psim::launch_update(s, count, *params, params->is_mouse_dragging > 0 ? 1 : 0,
                                     nullptr, nullptr, 0, t, stream));
     } else {

@@ -849,7 +849,9 @@ hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_
 {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
-    if (aos_streaming(n))
+    // nt sc1 stores write partial 128-byte lines through to memory, which is slow: the
+    // streaming form needs a line-aligned destination.
+    if (aos_streaming(n) && (reinterpret_cast<uintptr_t>(aos) & 127u) == 0)
         hipLaunchKernelGGL(export_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK),
                            aos_reserve(36864), stream,
                            s, first, n, reinterpret_cast<f32x4 *>(aos));
@@ -864,7 +866,10 @@ hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
 {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
-    if (aos_streaming(n))
+    // The SoA side stores 4 bytes per lane from particle `first` on: line-aligned only when
+    // `first` is a multiple of 32 particles (the arrays themselves start 4 KiB-aligned).
+    if (aos_streaming(n) && (first & 31u) == 0 &&
+        (reinterpret_cast<uintptr_t>(s.px) & 127u) == 0)
         hipLaunchKernelGGL(import_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK),
                            aos_reserve(20480), stream,
                            s, first, n, reinterpret_cast<const f32x4 *>(aos));

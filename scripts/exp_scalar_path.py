@@ -17,7 +17,8 @@ def main():
     v = owner.get_particle_buffer()
     params = psim.SimParams(is_mouse_dragging=1, mouse_position=(0.0, 0.0, 48.0))
     stream = owner.get_stream()
-    for name, off in (("aligned (vector kernel)", 0), ("4 bytes off (scalar kernel)", 4)):
+    for name, off in (("aligned (vector kernel)", 0), ("16 bytes off (vector kernel)", 16),
+                      ("64 bytes off (vector kernel)", 64), ("4 bytes off (scalar kernel)", 4)):
         arrays = [p + off for p in (v.px, v.py, v.pz, v.vx, v.vy, v.vz)]
         best = 1e9
         for _ in range(3):
