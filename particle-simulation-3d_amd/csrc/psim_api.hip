@@ -54,6 +54,7 @@ int fail(int code, const char *fmt, ...)
 
 constexpr uint64_t kUniformSeed = 69;          // the reference's own seed, mod.rs:170
 constexpr uint32_t kStageParticles = 1u << 22; // AoS staging chunk: 4 Mi particles = 256 MiB
+constexpr uint32_t kBounceParticles = 1u << 19; // page-locked bounce slot: 512 Ki particles = 32 MiB
 constexpr uint32_t kCapacityQuantum = 1024;    // particles; keeps every array 4 KiB-granular
 
 int env_int(const char *name, int dflt)
@@ -111,6 +112,8 @@ struct psim_handle {
     uint64_t *checksum_dev = nullptr;          // 8 x u64 inside the slab
     psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
     uint32_t stage_particles = 0;              // its size
+    psim_particle *bounce = nullptr;           // two page-locked slots for pageable downloads
+    hipEvent_t bounce_done[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     TuningOverrides overrides;
 };
@@ -385,6 +388,9 @@ PSIM_API void psim_destroy(psim_handle *h)
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->aos_stage) (void)hipFree(h->aos_stage);
+    if (h->bounce) (void)hipHostFree(h->bounce);
+    for (hipEvent_t e : h->bounce_done)
+        if (e) (void)hipEventDestroy(e);
     if (h->slab) (void)hipFree(h->slab);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -585,11 +591,84 @@ int enqueue_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first
     return PSIM_OK;
 }
 
+// True when `p` is ordinary (pageable) host memory, which the runtime copies out of the
+// device at a fraction of the link rate.
+bool is_pageable(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                      // unknown to the runtime: plain malloc memory
+        return true;
+    }
+    return a.type == hipMemoryTypeUnregistered;
+}
+
+void parallel_memcpy(void *dst, const void *src, size_t bytes)
+{
+    const size_t kThreads = 4, kMin = 4u << 20;
+    if (bytes < kMin) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = (bytes / kThreads + 4095) & ~(size_t)4095;
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < kThreads && t * per < bytes; ++t) {
+        const size_t lo = t * per, len = bytes - lo < per ? bytes - lo : per;
+        try {
+            pool.emplace_back(memcpy, (char *)dst + lo, (const char *)src + lo, len);
+        } catch (...) {
+            memcpy((char *)dst + lo, (const char *)src + lo, len);
+        }
+    }
+    memcpy(dst, src, per < bytes ? per : bytes);
+    for (auto &t : pool) t.join();
+}
+
+// Download into pageable memory: the device copies slot after slot into two page-locked
+// bounce slots at the link rate while host threads move the previous slot into `dst`
+// (the runtime's own pageable path reaches 10.7 GB/s; this one is bound by the host copy).
+int download_aos_bounced(psim_handle *h, psim_particle *dst, uint64_t first, uint64_t n)
+{
+    int rc = ensure_stage(h);
+    if (rc != PSIM_OK) return rc;
+    const uint64_t slot = kBounceParticles < h->stage_particles / 2 ? kBounceParticles
+                                                                     : (h->stage_particles + 1) / 2;
+    if (!h->bounce) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->bounce),
+                              2 * (size_t)kBounceParticles * sizeof(psim_particle),
+                              hipHostMallocDefault));
+        for (auto &e : h->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    uint64_t prev_off = 0, prev_m = 0, c = 0;
+    for (uint64_t done = 0; done < n; done += slot, ++c) {
+        const uint32_t m = (uint32_t)((n - done) < slot ? (n - done) : slot);
+        const int b = (int)(c & 1);
+        HIP_TRY(psim::launch_export_aos(h->soa, (uint32_t)(first + done), m,
+                                        h->aos_stage + b * slot, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->bounce + (uint64_t)b * kBounceParticles, h->aos_stage + b * slot,
+                               (size_t)m * sizeof(psim_particle), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->bounce_done[b], h->stream));
+        if (c > 0) {                                   // the previous slot, while this one travels
+            HIP_TRY(hipEventSynchronize(h->bounce_done[b ^ 1]));
+            parallel_memcpy(dst + prev_off, h->bounce + (uint64_t)(b ^ 1) * kBounceParticles,
+                            (size_t)prev_m * sizeof(psim_particle));
+        }
+        prev_off = done, prev_m = m;
+    }
+    const int last = (int)((c - 1) & 1);
+    HIP_TRY(hipEventSynchronize(h->bounce_done[last]));
+    parallel_memcpy(dst + prev_off, h->bounce + (uint64_t)last * kBounceParticles,
+                    (size_t)prev_m * sizeof(psim_particle));
+    return PSIM_OK;
+}
+
 }  // namespace
 
 PSIM_API int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n)
 {
     CHECK_HANDLE(h);
+    if (n && dst_host && check_range(h, first, n) == PSIM_OK && is_pageable(dst_host))
+        return download_aos_bounced(h, dst_host, first, n);
     int rc = enqueue_download_aos(h, dst_host, first, n);
     if (rc != PSIM_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
