@@ -662,6 +662,37 @@ int download_aos_bounced(psim_handle *h, psim_particle *dst, uint64_t first, uin
     return PSIM_OK;
 }
 
+// The way in from pageable memory, the same way round: host threads fill a page-locked slot
+// while the previous one travels to the device and is transposed there.
+int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first, uint64_t n)
+{
+    int rc = ensure_stage(h);
+    if (rc != PSIM_OK) return rc;
+    const uint64_t slot = kBounceParticles < h->stage_particles / 2 ? kBounceParticles
+                                                                     : (h->stage_particles + 1) / 2;
+    if (!h->bounce) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->bounce),
+                              2 * (size_t)kBounceParticles * sizeof(psim_particle),
+                              hipHostMallocDefault));
+        for (auto &e : h->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    uint64_t c = 0;
+    for (uint64_t done = 0; done < n; done += slot, ++c) {
+        const uint32_t m = (uint32_t)((n - done) < slot ? (n - done) : slot);
+        const int b = (int)(c & 1);
+        if (c >= 2) HIP_TRY(hipEventSynchronize(h->bounce_done[b]));      // slot consumed
+        psim_particle *host = h->bounce + (uint64_t)b * kBounceParticles;
+        parallel_memcpy(host, src + done, (size_t)m * sizeof(psim_particle));
+        HIP_TRY(hipMemcpyAsync(h->aos_stage + b * slot, host, (size_t)m * sizeof(psim_particle),
+                               hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)(first + done), m,
+                                        h->aos_stage + b * slot, h->stream));
+        HIP_TRY(hipEventRecord(h->bounce_done[b], h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
 }  // namespace
 
 PSIM_API int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n)
@@ -691,6 +722,7 @@ PSIM_API int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint
     if (n == 0) return PSIM_OK;
     if (!src_host) return fail(PSIM_ERR_INVALID, "null source");
     h->colours_changed = true;                   // the caller's colours, whatever they are
+    if (is_pageable(src_host)) return upload_aos_bounced(h, src_host, first, n);
     return upload_aos_chunked(h, src_host, first, n);
 }
 
