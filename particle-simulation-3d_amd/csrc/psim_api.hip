@@ -693,6 +693,47 @@ int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first,
     return PSIM_OK;
 }
 
+// Plain device <-> pageable host copies (the SoA transfers) through the same two slots.
+int bounce_bytes(psim_handle *h, void *host, void *dev, size_t bytes, bool to_host)
+{
+    if (!h->bounce) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->bounce),
+                              2 * (size_t)kBounceParticles * sizeof(psim_particle),
+                              hipHostMallocDefault));
+        for (auto &e : h->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const size_t slot = (size_t)kBounceParticles * sizeof(psim_particle);
+    char *pin = reinterpret_cast<char *>(h->bounce);
+    size_t prev_off = 0, prev_len = 0, c = 0;
+    for (size_t done = 0; done < bytes; done += slot, ++c) {
+        const size_t len = bytes - done < slot ? bytes - done : slot;
+        const int b = (int)(c & 1);
+        if (to_host) {
+            HIP_TRY(hipMemcpyAsync(pin + b * slot, (char *)dev + done, len, hipMemcpyDeviceToHost,
+                                   h->stream));
+            HIP_TRY(hipEventRecord(h->bounce_done[b], h->stream));
+            if (c > 0) {
+                HIP_TRY(hipEventSynchronize(h->bounce_done[b ^ 1]));
+                parallel_memcpy((char *)host + prev_off, pin + (b ^ 1) * slot, prev_len);
+            }
+            prev_off = done, prev_len = len;
+        } else {
+            if (c >= 2) HIP_TRY(hipEventSynchronize(h->bounce_done[b]));
+            parallel_memcpy(pin + b * slot, (const char *)host + done, len);
+            HIP_TRY(hipMemcpyAsync((char *)dev + done, pin + b * slot, len, hipMemcpyHostToDevice,
+                                   h->stream));
+            HIP_TRY(hipEventRecord(h->bounce_done[b], h->stream));
+        }
+    }
+    if (to_host && c > 0) {
+        const int last = (int)((c - 1) & 1);
+        HIP_TRY(hipEventSynchronize(h->bounce_done[last]));
+        parallel_memcpy((char *)host + prev_off, pin + last * slot, prev_len);
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
 }  // namespace
 
 PSIM_API int psim_download_aos(psim_handle *h, psim_particle *dst_host, uint64_t first, uint64_t n)
@@ -751,7 +792,14 @@ PSIM_API int psim_download_soa(psim_handle *h, float *dst_host, uint64_t first, 
     if (rc != PSIM_OK) return rc;
     if (n == 0) return PSIM_OK;
     if (!dst_host) return fail(PSIM_ERR_INVALID, "null destination");
-    const float *arr[6] = {h->soa.px, h->soa.py, h->soa.pz, h->soa.vx, h->soa.vy, h->soa.vz};
+    float *arr[6] = {h->soa.px, h->soa.py, h->soa.pz, h->soa.vx, h->soa.vy, h->soa.vz};
+    if (is_pageable(dst_host)) {
+        for (int k = 0; k < 6; ++k) {
+            rc = bounce_bytes(h, dst_host + (uint64_t)k * n, arr[k] + first, n * sizeof(float), true);
+            if (rc != PSIM_OK) return rc;
+        }
+        return PSIM_OK;
+    }
     for (int k = 0; k < 6; ++k)
         HIP_TRY(hipMemcpyAsync(dst_host + (uint64_t)k * n, arr[k] + first, n * sizeof(float),
                                hipMemcpyDeviceToHost, h->stream));
@@ -767,6 +815,14 @@ PSIM_API int psim_upload_soa(psim_handle *h, const float *src_host, uint64_t fir
     if (n == 0) return PSIM_OK;
     if (!src_host) return fail(PSIM_ERR_INVALID, "null source");
     float *arr[6] = {h->soa.px, h->soa.py, h->soa.pz, h->soa.vx, h->soa.vy, h->soa.vz};
+    if (is_pageable(src_host)) {
+        for (int k = 0; k < 6; ++k) {
+            rc = bounce_bytes(h, const_cast<float *>(src_host) + (uint64_t)k * n, arr[k] + first,
+                              n * sizeof(float), false);
+            if (rc != PSIM_OK) return rc;
+        }
+        return PSIM_OK;
+    }
     for (int k = 0; k < 6; ++k)
         HIP_TRY(hipMemcpyAsync(arr[k] + first, src_host + (uint64_t)k * n, n * sizeof(float),
                                hipMemcpyHostToDevice, h->stream));
