@@ -245,8 +245,10 @@ int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint64_t firs
  * reference keeps a host-side `Vec<Particle>` that it hands to the renderer every
  * frame (src/simulation/cpu.rs:8, :116-120); a caller that stages frames through
  * host memory the same way should take that buffer from here: copies into and out
- * of page-locked memory run at the full host-link rate, copies of pageable memory
- * at a fraction of it.  Free with psim_host_free (NULL is allowed). */
+ * of page-locked memory run at the full host-link rate and can be asynchronous;
+ * pageable memory is accepted everywhere too and is moved through page-locked bounce
+ * slots inside the library (slower, synchronous, and it costs host threads).  Free
+ * with psim_host_free (NULL is allowed). */
 int  psim_host_alloc(void **out, uint64_t bytes);
 void psim_host_free(void *ptr);
 
