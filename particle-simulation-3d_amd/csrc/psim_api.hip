@@ -203,15 +203,18 @@ int generate(psim_handle *h, int mode)
     int rc = ensure_stage(h);
     if (rc != PSIM_OK) return rc;
     struct Staging {
+        hipStream_t stream = nullptr;
         psim_particle *host = nullptr;
         hipEvent_t done[2] = {nullptr, nullptr};
         ~Staging()
         {
+            (void)hipStreamSynchronize(stream);      // an error path may leave copies in flight
             if (host) (void)hipHostFree(host);
             for (hipEvent_t e : done)
                 if (e) (void)hipEventDestroy(e);
         }
     } st;
+    st.stream = h->stream;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st.host),
                           (size_t)(slot_particles * slots) * sizeof(psim_particle),
                           hipHostMallocDefault));
@@ -624,6 +627,18 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes)
     for (auto &t : pool) t.join();
 }
 
+// The two page-locked bounce slots and their events, created on first use.
+int ensure_bounce(psim_handle *h)
+{
+    if (!h->bounce)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->bounce),
+                              2 * (size_t)kBounceParticles * sizeof(psim_particle),
+                              hipHostMallocDefault));
+    for (auto &e : h->bounce_done)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return PSIM_OK;
+}
+
 // Download into pageable memory: the device copies slot after slot into two page-locked
 // bounce slots at the link rate while host threads move the previous slot into `dst`
 // (the runtime's own pageable path reaches 10.7 GB/s; this one is bound by the host copy).
@@ -633,12 +648,8 @@ int download_aos_bounced(psim_handle *h, psim_particle *dst, uint64_t first, uin
     if (rc != PSIM_OK) return rc;
     const uint64_t slot = kBounceParticles < h->stage_particles / 2 ? kBounceParticles
                                                                      : (h->stage_particles + 1) / 2;
-    if (!h->bounce) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->bounce),
-                              2 * (size_t)kBounceParticles * sizeof(psim_particle),
-                              hipHostMallocDefault));
-        for (auto &e : h->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    rc = ensure_bounce(h);
+    if (rc != PSIM_OK) return rc;
     uint64_t prev_off = 0, prev_m = 0, c = 0;
     for (uint64_t done = 0; done < n; done += slot, ++c) {
         const uint32_t m = (uint32_t)((n - done) < slot ? (n - done) : slot);
@@ -670,12 +681,8 @@ int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first,
     if (rc != PSIM_OK) return rc;
     const uint64_t slot = kBounceParticles < h->stage_particles / 2 ? kBounceParticles
                                                                      : (h->stage_particles + 1) / 2;
-    if (!h->bounce) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->bounce),
-                              2 * (size_t)kBounceParticles * sizeof(psim_particle),
-                              hipHostMallocDefault));
-        for (auto &e : h->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    rc = ensure_bounce(h);
+    if (rc != PSIM_OK) return rc;
     uint64_t c = 0;
     for (uint64_t done = 0; done < n; done += slot, ++c) {
         const uint32_t m = (uint32_t)((n - done) < slot ? (n - done) : slot);
@@ -696,12 +703,8 @@ int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first,
 // Plain device <-> pageable host copies (the SoA transfers) through the same two slots.
 int bounce_bytes(psim_handle *h, void *host, void *dev, size_t bytes, bool to_host)
 {
-    if (!h->bounce) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->bounce),
-                              2 * (size_t)kBounceParticles * sizeof(psim_particle),
-                              hipHostMallocDefault));
-        for (auto &e : h->bounce_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    int rc = ensure_bounce(h);
+    if (rc != PSIM_OK) return rc;
     const size_t slot = (size_t)kBounceParticles * sizeof(psim_particle);
     char *pin = reinterpret_cast<char *>(h->bounce);
     size_t prev_off = 0, prev_len = 0, c = 0;
@@ -891,7 +894,8 @@ PSIM_API int psim_checksum(psim_handle *h, uint64_t out[6])
     if (!out) return fail(PSIM_ERR_INVALID, "null output");
     // One 256-thread workgroup per CU reads fastest (100 M particles, GB/s of the 24 B read:
     // 128 workgroups 4.2 k, 256 6.8 k, 512 6.4 k, 4096 5.8 k).
-    const int blocks = env_int("PSIM_CHECKSUM_BLOCKS", h->num_cus);
+    int blocks = env_int("PSIM_CHECKSUM_BLOCKS", h->num_cus);
+    if (blocks < 1) blocks = h->num_cus > 0 ? h->num_cus : 256;
     HIP_TRY(psim::launch_checksum(h->soa, h->count, h->checksum_dev, (uint32_t)blocks, h->stream));
     HIP_TRY(hipMemcpyAsync(out, h->checksum_dev, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost,
                            h->stream));
@@ -918,10 +922,8 @@ PSIM_API int psim_device(const psim_handle *h) { return h ? h->device : -1; }
 PSIM_API int psim_timer_start(psim_handle *h)
 {
     CHECK_HANDLE(h);
-    if (!h->ev_start) {
-        HIP_TRY(hipEventCreate(&h->ev_start));
-        HIP_TRY(hipEventCreate(&h->ev_stop));
-    }
+    if (!h->ev_start) HIP_TRY(hipEventCreate(&h->ev_start));
+    if (!h->ev_stop) HIP_TRY(hipEventCreate(&h->ev_stop));
     HIP_TRY(hipEventRecord(h->ev_start, h->stream));
     return PSIM_OK;
 }
@@ -930,7 +932,8 @@ PSIM_API int psim_timer_stop(psim_handle *h, float *elapsed_ms)
 {
     CHECK_HANDLE(h);
     if (!elapsed_ms) return fail(PSIM_ERR_INVALID, "null output");
-    if (!h->ev_start) return fail(PSIM_ERR_INVALID, "psim_timer_stop without psim_timer_start");
+    if (!h->ev_start || !h->ev_stop)
+        return fail(PSIM_ERR_INVALID, "psim_timer_stop without psim_timer_start");
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev_stop));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));

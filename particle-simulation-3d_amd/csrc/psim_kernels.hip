@@ -748,20 +748,21 @@ hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_firs
 // The 64-byte record (src/simulation/mod.rs:86-98) is four 16-byte quads:
 //   q0 = position.xyz, padding1   q1 = velocity.xyz, padding2
 //   q2 = color                    q3 = initial_color
-// A workgroup moves PSIM_BLOCK particles = 16 KiB of AoS.  The AoS side is
-// accessed as a linear run of quads (lane t touches quad k*PSIM_BLOCK + t, so a
+// A workgroup of BLOCK threads (256, or one wave) moves BLOCK particles = BLOCK * 64 bytes
+// of AoS.  The AoS side is
+// accessed as a linear run of quads (lane t touches quad k*BLOCK + t, so a
 // wave instruction covers 1 KiB of consecutive bytes); the transposition happens
 // in LDS.  LDS holds quads at [field][particle]; the per-particle side is lane-linear,
 // and the rows are padded so that the AoS-order side (lane t -> [t & 3][k*64 + t/4]) is
 // free of bank conflicts too: by 4 quads for the 16-byte reads of the export (banks
 // taken modulo 64 dwords), by 2 quads for the 16-byte writes of the import (modulo 32).
 
-template <bool NT>
-__global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint32_t first,
+template <bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) export_aos_kernel(SoaPtrs s, uint32_t first,
                                                                uint32_t n, f32x4 *aos)
 {
-    __shared__ f32x4 tile[4][PSIM_BLOCK + 4];
-    const uint32_t base = blockIdx.x * PSIM_BLOCK;            // first particle of the tile
+    __shared__ f32x4 tile[4][BLOCK + 4];
+    const uint32_t base = blockIdx.x * BLOCK;            // first particle of the tile
     const uint32_t t = threadIdx.x;
     const uint32_t i = base + t;
     if (i < n) {
@@ -773,31 +774,31 @@ __global__ void __launch_bounds__(PSIM_BLOCK) export_aos_kernel(SoaPtrs s, uint3
         tile[3][t] = ld<NT>(reinterpret_cast<const f32x4 *>(s.initial_color) + src);
     }
     __syncthreads();
-    const uint32_t live = (n - base) < PSIM_BLOCK ? (n - base) : PSIM_BLOCK;
+    const uint32_t live = (n - base) < BLOCK ? (n - base) : BLOCK;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t q = k * PSIM_BLOCK + t;                // quad index within the tile
+        const uint32_t q = k * BLOCK + t;                // quad index within the tile
         const uint32_t particle = q >> 2, field = q & 3u;
         if constexpr (NT) {
             st_stream(aos, 4ull * base + (q & ~63u), 4ull * n, t & 63u,
-                      tile[field][particle < PSIM_BLOCK ? particle : 0]);
+                      tile[field][particle < BLOCK ? particle : 0]);
         } else {
             if (particle < live) st<NT>(aos + 4ull * base + q, tile[field][particle]);
         }
     }
 }
 
-template <bool NT>
-__global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint32_t first,
+template <bool NT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) import_aos_kernel(SoaPtrs s, uint32_t first,
                                                                uint32_t n, const f32x4 *aos)
 {
-    __shared__ f32x4 tile[4][PSIM_BLOCK + 2];
-    const uint32_t base = blockIdx.x * PSIM_BLOCK;
+    __shared__ f32x4 tile[4][BLOCK + 2];
+    const uint32_t base = blockIdx.x * BLOCK;
     const uint32_t t = threadIdx.x;
-    const uint32_t live = (n - base) < PSIM_BLOCK ? (n - base) : PSIM_BLOCK;
+    const uint32_t live = (n - base) < BLOCK ? (n - base) : BLOCK;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t q = k * PSIM_BLOCK + t;
+        const uint32_t q = k * BLOCK + t;
         const uint32_t particle = q >> 2, field = q & 3u;
         if (particle < live) tile[field][particle] = ld<NT>(aos + 4ull * base + q);
     }
@@ -826,22 +827,35 @@ __global__ void __launch_bounds__(PSIM_BLOCK) import_aos_kernel(SoaPtrs s, uint3
 }
 
 // Launch shape of the transposes, measured at 100 M particles (GB/s of the 128 B per
-// particle moved): plain, 32 waves per CU 5.34 k (export) / 5.36 k (import); non-temporal
-// 5.5-5.6 k; non-temporal + LDS reservation 36864 B (3 workgroups = 12 waves per CU)
-// export 6.3-6.4 k, + 20480 B (4 workgroups) import 6.33-6.35 k; larger reservations fall
-// off (2 workgroups: 4.3 k / 2.8 k).  The import is sensitive beyond the workgroup count:
-// 16384 B and 24064 B also leave 4 workgroups per CU but reach only 6.0-6.1 k, repeatably.
-// Small transfers stay plain: they are cache-resident.
+// particle moved): plain, 32 waves per CU 5.34 k (export) / 5.36 k (import); with streaming
+// accesses and, through an LDS reservation, fewer resident waves per CU:
+//   export, 256-thread workgroups + 36864 B (3 workgroups = 12 waves) 6.46-6.6 k;
+//           64-thread workgroups + 6144 B (15 waves) the same, 6.48-6.51 k
+//   import, 256-thread workgroups + 20480 B (4 workgroups) 6.1 k;
+//           64-thread workgroups + 6144 B / 7168 B (15 / 14 waves) 6.37-6.40 k,
+//           4096 B (19 waves) 6.17 k, 8192 B (13 waves) 5.9 k, 16384 B (7 waves) 4.1 k
+// The import gains from single-wave workgroups because no wave then waits at the barrier
+// for the other three waves' loads.  Small transfers stay plain: they are cache-resident.
 static bool aos_streaming(uint32_t n) { return (uint64_t)n * 128u > 400000000ull; }
 
-// Experiments only: PSIM_AOS_RESERVE overrides the LDS reservation of both transposes.
+// Experiments only: PSIM_AOS_RESERVE overrides the LDS reservation of both transposes,
+// PSIM_AOS_BLOCK (64 or 256) the workgroup size of their streaming forms.
+static int aos_env(const char *name)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : -1;
+}
+
 static uint32_t aos_reserve(uint32_t automatic)
 {
-    static const int v = [] {
-        const char *e = getenv("PSIM_AOS_RESERVE");
-        return e && *e ? atoi(e) : -1;
-    }();
+    static const int v = aos_env("PSIM_AOS_RESERVE");
     return v >= 0 ? (uint32_t)v : automatic;
+}
+
+static uint32_t aos_block(uint32_t automatic)
+{
+    static const int v = aos_env("PSIM_AOS_BLOCK");
+    return v == 64 || v == (int)PSIM_BLOCK ? (uint32_t)v : automatic;
 }
 
 hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
@@ -849,15 +863,18 @@ hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_
 {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    f32x4 *dst = reinterpret_cast<f32x4 *>(aos);
     // nt sc1 stores write partial 128-byte lines through to memory, which is slow: the
     // streaming form needs a line-aligned destination.
-    if (aos_streaming(n) && (reinterpret_cast<uintptr_t>(aos) & 127u) == 0)
-        hipLaunchKernelGGL(export_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK),
-                           aos_reserve(36864), stream,
-                           s, first, n, reinterpret_cast<f32x4 *>(aos));
+    if (!aos_streaming(n) || (reinterpret_cast<uintptr_t>(aos) & 127u) != 0)
+        hipLaunchKernelGGL((export_aos_kernel<false, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK), 0,
+                           stream, s, first, n, dst);
+    else if (aos_block(PSIM_BLOCK) == 64u)
+        hipLaunchKernelGGL((export_aos_kernel<true, 64>), dim3((n + 63u) / 64u), dim3(64),
+                           aos_reserve(6144), stream, s, first, n, dst);
     else
-        hipLaunchKernelGGL(export_aos_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s,
-                           first, n, reinterpret_cast<f32x4 *>(aos));
+        hipLaunchKernelGGL((export_aos_kernel<true, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK),
+                           aos_reserve(36864), stream, s, first, n, dst);
     return hipGetLastError();
 }
 
@@ -866,16 +883,18 @@ hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
 {
     if (n == 0) return hipSuccess;
     const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(aos);
     // The SoA side stores 4 bytes per lane from particle `first` on: line-aligned only when
     // `first` is a multiple of 32 particles (the arrays themselves start 4 KiB-aligned).
-    if (aos_streaming(n) && (first & 31u) == 0 &&
-        (reinterpret_cast<uintptr_t>(s.px) & 127u) == 0)
-        hipLaunchKernelGGL(import_aos_kernel<true>, dim3(grid), dim3(PSIM_BLOCK),
-                           aos_reserve(20480), stream,
-                           s, first, n, reinterpret_cast<const f32x4 *>(aos));
+    if (!aos_streaming(n) || (first & 31u) != 0 || (reinterpret_cast<uintptr_t>(s.px) & 127u) != 0)
+        hipLaunchKernelGGL((import_aos_kernel<false, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK), 0,
+                           stream, s, first, n, src);
+    else if (aos_block(64) == 64u)
+        hipLaunchKernelGGL((import_aos_kernel<true, 64>), dim3((n + 63u) / 64u), dim3(64),
+                           aos_reserve(6144), stream, s, first, n, src);
     else
-        hipLaunchKernelGGL(import_aos_kernel<false>, dim3(grid), dim3(PSIM_BLOCK), 0, stream, s,
-                           first, n, reinterpret_cast<const f32x4 *>(aos));
+        hipLaunchKernelGGL((import_aos_kernel<true, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK),
+                           aos_reserve(20480), stream, s, first, n, src);
     return hipGetLastError();
 }
 
