@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "psim_kernels.h"
 #include "psim_threshold.h"
 
@@ -834,16 +836,23 @@ __global__ void __launch_bounds__(BLOCK) import_aos_kernel(SoaPtrs s, uint32_t f
 //   import, 256-thread workgroups + 20480 B (4 workgroups) 6.1 k;
 //           64-thread workgroups + 6144 B / 7168 B (15 / 14 waves) 6.37-6.40 k,
 //           4096 B (19 waves) 6.17 k, 8192 B (13 waves) 5.9 k, 16384 B (7 waves) 4.1 k
-// The import gains from single-wave workgroups because no wave then waits at the barrier
-// for the other three waves' loads.  Small transfers stay plain: they are cache-resident.
-static bool aos_streaming(uint32_t n) { return (uint64_t)n * 128u > 400000000ull; }
-
+// Single-wave workgroups gain because no wave waits at a barrier for the other three
+// waves' loads; they are ahead at every size (1 M particles, plain: export 6.50 -> 6.63 k,
+// import 6.25 -> 6.77 k).  Plain accesses win while the SoA and AoS sides together fit the
+// 256 MiB Infinity Cache (2 M particles: 7.0-7.1 k against 6.2 / 5.8 k streaming), streaming
+// from 2.5 M particles on (6.2 / 5.9 k against 5.9 / 5.8 k).
 // Experiments only: PSIM_AOS_RESERVE overrides the LDS reservation of both transposes,
-// PSIM_AOS_BLOCK (64 or 256) the workgroup size of their streaming forms.
+// PSIM_AOS_BLOCK (64 or 256) their workgroup size, PSIM_AOS_STREAM (0 / 1) the access form.
 static int aos_env(const char *name)
 {
     const char *e = getenv(name);
     return e && *e ? atoi(e) : -1;
+}
+
+static bool aos_streaming(uint32_t n)
+{
+    static const int v = aos_env("PSIM_AOS_STREAM");
+    return v >= 0 ? v != 0 : (uint64_t)n * 128u > 288000000ull;
 }
 
 static uint32_t aos_reserve(uint32_t automatic)
@@ -852,29 +861,47 @@ static uint32_t aos_reserve(uint32_t automatic)
     return v >= 0 ? (uint32_t)v : automatic;
 }
 
-static uint32_t aos_block(uint32_t automatic)
+static bool aos_single_wave()
 {
     static const int v = aos_env("PSIM_AOS_BLOCK");
-    return v == 64 || v == (int)PSIM_BLOCK ? (uint32_t)v : automatic;
+    return v != (int)PSIM_BLOCK;
+}
+
+template <bool NT, typename Pointer>
+static void launch_transpose(const SoaPtrs &s, uint32_t first, uint32_t n,
+                             Pointer aos, uint32_t reserve, uint32_t reserve_256,
+                             hipStream_t stream)
+{
+    if (aos_single_wave()) {
+        const dim3 grid((n + 63u) / 64u), block(64);
+        if constexpr (std::is_const_v<std::remove_pointer_t<Pointer>>)
+            hipLaunchKernelGGL((import_aos_kernel<NT, 64>), grid, block, aos_reserve(reserve),
+                               stream, s, first, n, aos);
+        else
+            hipLaunchKernelGGL((export_aos_kernel<NT, 64>), grid, block, aos_reserve(reserve),
+                               stream, s, first, n, aos);
+    } else {
+        const dim3 grid((n + PSIM_BLOCK - 1u) / PSIM_BLOCK), block(PSIM_BLOCK);
+        if constexpr (std::is_const_v<std::remove_pointer_t<Pointer>>)
+            hipLaunchKernelGGL((import_aos_kernel<NT, PSIM_BLOCK>), grid, block,
+                               aos_reserve(reserve_256), stream, s, first, n, aos);
+        else
+            hipLaunchKernelGGL((export_aos_kernel<NT, PSIM_BLOCK>), grid, block,
+                               aos_reserve(reserve_256), stream, s, first, n, aos);
+    }
 }
 
 hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
                              hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
     f32x4 *dst = reinterpret_cast<f32x4 *>(aos);
     // nt sc1 stores write partial 128-byte lines through to memory, which is slow: the
     // streaming form needs a line-aligned destination.
-    if (!aos_streaming(n) || (reinterpret_cast<uintptr_t>(aos) & 127u) != 0)
-        hipLaunchKernelGGL((export_aos_kernel<false, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK), 0,
-                           stream, s, first, n, dst);
-    else if (aos_block(PSIM_BLOCK) == 64u)
-        hipLaunchKernelGGL((export_aos_kernel<true, 64>), dim3((n + 63u) / 64u), dim3(64),
-                           aos_reserve(6144), stream, s, first, n, dst);
+    if (aos_streaming(n) && (reinterpret_cast<uintptr_t>(aos) & 127u) == 0)
+        launch_transpose<true>(s, first, n, dst, 6144, 36864, stream);
     else
-        hipLaunchKernelGGL((export_aos_kernel<true, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK),
-                           aos_reserve(36864), stream, s, first, n, dst);
+        launch_transpose<false>(s, first, n, dst, n >= (1u << 20) ? 6144 : 0, 0, stream);
     return hipGetLastError();
 }
 
@@ -882,19 +909,13 @@ hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
                              const psim_particle *aos, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t grid = (n + PSIM_BLOCK - 1u) / PSIM_BLOCK;
     const f32x4 *src = reinterpret_cast<const f32x4 *>(aos);
     // The SoA side stores 4 bytes per lane from particle `first` on: line-aligned only when
     // `first` is a multiple of 32 particles (the arrays themselves start 4 KiB-aligned).
-    if (!aos_streaming(n) || (first & 31u) != 0 || (reinterpret_cast<uintptr_t>(s.px) & 127u) != 0)
-        hipLaunchKernelGGL((import_aos_kernel<false, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK), 0,
-                           stream, s, first, n, src);
-    else if (aos_block(64) == 64u)
-        hipLaunchKernelGGL((import_aos_kernel<true, 64>), dim3((n + 63u) / 64u), dim3(64),
-                           aos_reserve(6144), stream, s, first, n, src);
+    if (aos_streaming(n) && (first & 31u) == 0 && (reinterpret_cast<uintptr_t>(s.px) & 127u) == 0)
+        launch_transpose<true>(s, first, n, src, 6144, 20480, stream);
     else
-        hipLaunchKernelGGL((import_aos_kernel<true, PSIM_BLOCK>), dim3(grid), dim3(PSIM_BLOCK),
-                           aos_reserve(20480), stream, s, first, n, src);
+        launch_transpose<false>(s, first, n, src, n >= (1u << 20) ? 6144 : 0, 0, stream);
     return hipGetLastError();
 }
 

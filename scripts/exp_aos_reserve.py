@@ -28,7 +28,7 @@ def child(n):
                 fn()
             best = min(best, sim.timer_stop() / 10)
         out.append(128 * n / best / 1e6)
-    print(f"block {os.environ.get('PSIM_AOS_BLOCK', '256'):>3} reserve {os.environ.get('PSIM_AOS_RESERVE', 'auto'):>6}: export {out[0]:7.1f} GB/s  "
+    print(f"block {os.environ.get('PSIM_AOS_BLOCK', 'auto'):>4} reserve {os.environ.get('PSIM_AOS_RESERVE', 'auto'):>6}: export {out[0]:7.1f} GB/s  "
           f"import {out[1]:7.1f} GB/s", flush=True)
 
 
