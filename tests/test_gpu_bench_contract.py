@@ -71,6 +71,28 @@ def test_two_rank_control_flow_rehearsal():
     assert abs(out["value"] - 2 * n * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-6
 
 
+def test_one_rank_under_the_launcher_uses_rccl():
+    """The driver's launch line with one rank: the process group is RCCL ("nccl"), the
+    barriers carry device ids and the max-over-ranks reduction runs on a GPU tensor -- the
+    same calls the N > 1 runs make."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PSIM_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    n = 1_000_000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", os.path.join(T.ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "5", "--warmup", "2", "--particles", str(n),
+                        "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:1000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["total_particles"] == n
+    assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+
+
 def test_multi_workload_line():
     out = run_bench("--workload", "multi", "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and "cpu_baseline" not in out
