@@ -831,14 +831,15 @@ __global__ void __launch_bounds__(BLOCK) import_aos_kernel(SoaPtrs s, uint32_t f
 // Launch shape of the transposes, measured at 100 M particles (GB/s of the 128 B per
 // particle moved): plain, 32 waves per CU 5.34 k (export) / 5.36 k (import); with streaming
 // accesses and, through an LDS reservation, fewer resident waves per CU:
-//   export, 256-thread workgroups + 36864 B (3 workgroups = 12 waves) 6.46-6.6 k;
-//           64-thread workgroups + 6144 B (15 waves) the same, 6.48-6.51 k
+//   export, 256-thread workgroups + 36864 B (3 workgroups = 12 waves) 6.47-6.6 k;
+//           64-thread workgroups + 6144 B (15 waves) 6.24-6.5 k, 3 % behind back to back
 //   import, 256-thread workgroups + 20480 B (4 workgroups) 6.1 k;
 //           64-thread workgroups + 6144 B / 7168 B (15 / 14 waves) 6.37-6.40 k,
 //           4096 B (19 waves) 6.17 k, 8192 B (13 waves) 5.9 k, 16384 B (7 waves) 4.1 k
-// Single-wave workgroups gain because no wave waits at a barrier for the other three
-// waves' loads; they are ahead at every size (1 M particles, plain: export 6.50 -> 6.63 k,
-// import 6.25 -> 6.77 k).  Plain accesses win while the SoA and AoS sides together fit the
+// The import gains from single-wave workgroups because no wave waits at a barrier for the
+// other three waves' loads; the streaming export keeps 256 threads; at cache-resident sizes
+// single waves are ahead for both (1 M particles, plain: export 6.50 -> 6.63 k, import
+// 6.25 -> 6.77 k).  Plain accesses win while the SoA and AoS sides together fit the
 // 256 MiB Infinity Cache (2 M particles: 7.0-7.1 k against 6.2 / 5.8 k streaming), streaming
 // from 2.5 M particles on (6.2 / 5.9 k against 5.9 / 5.8 k).
 // Experiments only: PSIM_AOS_RESERVE overrides the LDS reservation of both transposes,
@@ -861,18 +862,18 @@ static uint32_t aos_reserve(uint32_t automatic)
     return v >= 0 ? (uint32_t)v : automatic;
 }
 
-static bool aos_single_wave()
+static bool aos_single_wave(bool automatic)
 {
     static const int v = aos_env("PSIM_AOS_BLOCK");
-    return v != (int)PSIM_BLOCK;
+    return v == 64 ? true : (v == (int)PSIM_BLOCK ? false : automatic);
 }
 
 template <bool NT, typename Pointer>
 static void launch_transpose(const SoaPtrs &s, uint32_t first, uint32_t n,
-                             Pointer aos, uint32_t reserve, uint32_t reserve_256,
-                             hipStream_t stream)
+                             Pointer aos, bool single_wave, uint32_t reserve,
+                             uint32_t reserve_256, hipStream_t stream)
 {
-    if (aos_single_wave()) {
+    if (aos_single_wave(single_wave)) {
         const dim3 grid((n + 63u) / 64u), block(64);
         if constexpr (std::is_const_v<std::remove_pointer_t<Pointer>>)
             hipLaunchKernelGGL((import_aos_kernel<NT, 64>), grid, block, aos_reserve(reserve),
@@ -899,9 +900,9 @@ hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_
     // nt sc1 stores write partial 128-byte lines through to memory, which is slow: the
     // streaming form needs a line-aligned destination.
     if (aos_streaming(n) && (reinterpret_cast<uintptr_t>(aos) & 127u) == 0)
-        launch_transpose<true>(s, first, n, dst, 6144, 36864, stream);
+        launch_transpose<true>(s, first, n, dst, false, 6144, 36864, stream);
     else
-        launch_transpose<false>(s, first, n, dst, n >= (1u << 20) ? 6144 : 0, 0, stream);
+        launch_transpose<false>(s, first, n, dst, true, n >= (1u << 20) ? 6144 : 0, 0, stream);
     return hipGetLastError();
 }
 
@@ -913,9 +914,9 @@ hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
     // The SoA side stores 4 bytes per lane from particle `first` on: line-aligned only when
     // `first` is a multiple of 32 particles (the arrays themselves start 4 KiB-aligned).
     if (aos_streaming(n) && (first & 31u) == 0 && (reinterpret_cast<uintptr_t>(s.px) & 127u) == 0)
-        launch_transpose<true>(s, first, n, src, 6144, 20480, stream);
+        launch_transpose<true>(s, first, n, src, true, 6144, 20480, stream);
     else
-        launch_transpose<false>(s, first, n, src, n >= (1u << 20) ? 6144 : 0, 0, stream);
+        launch_transpose<false>(s, first, n, src, true, n >= (1u << 20) ? 6144 : 0, 0, stream);
     return hipGetLastError();
 }
 

@@ -58,7 +58,7 @@ def main():
          lambda: sim.update_multi_device(P(), attr_buf, 8)),
         ("update_batch_kernel<2>", "16 fused steps", 48 * n,
          lambda: sim.update_batch(batch)),
-        ("export_aos_kernel<true, 64>", "SoA -> 64-byte records", 128 * n,
+        ("export_aos_kernel<true, 256>", "SoA -> 64-byte records", 128 * n,
          lambda: sim.export_aos_device(aos_buf)),
         ("import_aos_kernel<true, 64>", "64-byte records -> SoA", 128 * n,
          lambda: sim.import_aos_device(aos_buf)),
