@@ -126,7 +126,10 @@ enum {
 /* Replaces `ParticleSimulation::new` (src/simulation/mod.rs:22-29; call sites
  * src/app.rs:106-125, 182-195).  The wgpu device / surface-format arguments are
  * dropped; `device_id` selects the GPU.  Allocates SoA storage for `count`
- * particles, fills it with `generation_mode`, creates the handle's stream. */
+ * particles (at most PSIM_MAX_PARTICLES), fills it with `generation_mode`, creates the
+ * handle's stream. */
+#define PSIM_MAX_PARTICLES 0xFFFFFC00u   /* counts are u32 like the reference's; storage is
+                                            rounded up to multiples of 1024 particles */
 int psim_create(psim_handle **out, uint32_t count, int generation_mode, int device_id);
 
 /* Same, for one shard of a larger particle array that is partitioned across

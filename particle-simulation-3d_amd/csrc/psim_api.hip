@@ -120,11 +120,13 @@ struct psim_handle {
 
 namespace {
 
+constexpr uint32_t kMaxParticles = PSIM_MAX_PARTICLES;   // largest multiple of the quantum in 32 bits
+
+// Callers have checked n <= kMaxParticles.
 uint32_t round_capacity(uint32_t n)
 {
     uint64_t c = ((uint64_t)n + kCapacityQuantum - 1) / kCapacityQuantum * kCapacityQuantum;
     if (c == 0) c = kCapacityQuantum;
-    if (c > 0xFFFFFC00ull) c = 0xFFFFFC00ull;
     return (uint32_t)c;
 }
 
@@ -301,6 +303,9 @@ int create_impl(psim_handle **out, uint32_t count, uint64_t global_first, uint64
     if (global_count && (global_first > global_count || count > global_count - global_first))
         return fail(PSIM_ERR_INVALID, "shard [%llu, +%u) exceeds global count %llu",
                     (unsigned long long)global_first, count, (unsigned long long)global_count);
+    if (count > kMaxParticles)
+        return fail(PSIM_ERR_INVALID, "%u particles exceed the maximum of %u per handle", count,
+                    kMaxParticles);
     if (global_count > 0xFFFFFFFFull && generation_mode != PSIM_GEN_UNIFORM)
         return fail(PSIM_ERR_INVALID, "the reference generators index particles with u32");
     int ndev = 0;
@@ -527,6 +532,9 @@ PSIM_API int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode
         return fail(PSIM_ERR_INVALID, "unknown generation mode %d", generation_mode);
     h->generation_mode = generation_mode;            // compute.rs:153
     if (new_count == h->count) return PSIM_OK;       // compute.rs:155-157
+    if (new_count > kMaxParticles)
+        return fail(PSIM_ERR_INVALID, "%u particles exceed the maximum of %u per handle",
+                    new_count, kMaxParticles);
     if (h->global_count)
         return fail(PSIM_ERR_INVALID, "a shard cannot be resized; recreate the shards");
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -108,6 +108,8 @@ def test_null_arguments_are_rejected_without_a_device():
     assert b"null" in lib.psim_last_error()
     h = ctypes.c_void_p()
     assert lib.psim_create(ctypes.byref(h), 10, 99, 0) == 1     # unknown generation mode
+    assert lib.psim_create(ctypes.byref(h), 0xFFFFFFFF, 2, 0) == 1  # beyond PSIM_MAX_PARTICLES
+    assert b"exceed" in lib.psim_last_error()
     assert lib.psim_update(None, ctypes.byref(psim.SimParams())) == 1
     assert lib.psim_particle_count(None) == 0
     assert lib.psim_is_paused(None) == 0
