@@ -91,7 +91,8 @@ enum {
     PSIM_ERR_INVALID   = 1,   /* bad argument (null, out of range, misaligned) */
     PSIM_ERR_HIP       = 2,   /* a HIP runtime call failed */
     PSIM_ERR_NOMEM     = 3,   /* device or host allocation failed */
-    PSIM_ERR_NO_DEVICE = 4    /* no usable gfx950 device */
+    PSIM_ERR_NO_DEVICE = 4,   /* no usable gfx950 device */
+    PSIM_ERR_IO        = 5    /* a checkpoint file could not be opened, read or written */
 };
 
 /* `enum SphereGeneration` (src/simulation/mod.rs:15-19) plus the synthetic
@@ -283,6 +284,44 @@ int psim_device_soa(psim_handle *h, psim_soa_view *view);
  * Synchronous.  No counterpart in the reference; lets a caller verify a
  * multi-gigabyte state without downloading it. */
 int psim_checksum(psim_handle *h, uint64_t out[6]);
+
+/* ---- checkpoints ---------------------------------------------------------- */
+
+/* A checkpoint file is this 64-byte header followed by the particles of the whole set as
+ * 64-byte `Particle` records (src/simulation/mod.rs:86-98) in index order -- the layout
+ * every consumer of the reference's particle buffer already reads.  All fields
+ * little-endian.  The reference has no persistence of its own; this is what its record
+ * layout makes cheap. */
+typedef struct psim_checkpoint_header {
+    char     magic[8];          /* "PSIMCKP1" */
+    uint32_t version;           /* 1 */
+    uint32_t record_bytes;      /* 64 */
+    uint64_t particle_count;    /* particles in the whole set (all shards) */
+    uint64_t step;              /* the caller's step counter, stored and returned as is */
+    uint32_t generation_mode;   /* the mode the handle last generated with */
+    uint32_t color_semantics;   /* PSIM_COLOR_* of the writing handle */
+    uint8_t  reserved[24];      /* zero */
+} psim_checkpoint_header;
+
+/* Writes the handle's particles to `path` (created when missing), streaming them through
+ * page-locked memory while the file writes proceed.  A plain handle invalidates the header
+ * first and writes it last, so an interrupted write leaves no valid file, and truncates the
+ * file to its exact size.  A shard writes only its own records, at their place in the
+ * whole-set file; the shard that owns particle 0 also writes the header, the one that owns
+ * the last particle sets the file size: the caller runs every shard's call (any order, also
+ * at the same time) and treats the file as complete when all have returned.  Data goes
+ * through the page cache; no fsync.  Synchronous. */
+int psim_checkpoint_write(psim_handle *h, const char *path, uint64_t step);
+
+/* Restores the handle's particles from `path`: the header's particle_count must equal the
+ * handle's whole-set count (so a file written by one sharding restores into any other).
+ * `step_out` (optional) receives the stored step counter.  The handle's generation mode and
+ * colour semantics are left as they are.  Stepping on from a restored state gives the
+ * results the writing run would have got.  Synchronous. */
+int psim_checkpoint_read(psim_handle *h, const char *path, uint64_t *step_out);
+
+/* Reads and validates the header of `path` only; needs no device. */
+int psim_checkpoint_info(const char *path, psim_checkpoint_header *out);
 
 /* ---- streams -------------------------------------------------------------- */
 

@@ -189,6 +189,18 @@ public:
         check(psim_upload_aos(h_, particles.data(), first, particles.size()));
     }
 
+    // Checkpoints (no counterpart in the reference): header + the 64-byte records.
+    void save_checkpoint(const std::string &path, uint64_t step = 0)
+    {
+        check(psim_checkpoint_write(h_, path.c_str(), step));
+    }
+    uint64_t load_checkpoint(const std::string &path)
+    {
+        uint64_t step = 0;
+        check(psim_checkpoint_read(h_, path.c_str(), &step));
+        return step;
+    }
+
     psim_handle *handle() { return h_; }
 
 private:

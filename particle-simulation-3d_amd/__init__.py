@@ -115,6 +115,17 @@ class LaunchShapeInfo(ctypes.Structure):
 
 ACCESS_PLAIN, ACCESS_RESIDENT, ACCESS_STREAM = 0, 1, 2
 
+
+class CheckpointHeader(ctypes.Structure):
+    """`psim_checkpoint_header`: the 64 bytes at the start of a checkpoint file."""
+
+    _fields_ = [("magic", ctypes.c_char * 8), ("version", c_uint32), ("record_bytes", c_uint32),
+                ("particle_count", c_uint64), ("step", c_uint64), ("generation_mode", c_uint32),
+                ("color_semantics", c_uint32), ("reserved", ctypes.c_uint8 * 24)]
+
+
+assert ctypes.sizeof(CheckpointHeader) == 64
+
 _P = c_void_p
 ABI = {
     "psim_launch_shape": (c_int, [c_uint32, c_uint32, POINTER(LaunchShapeInfo)]),
@@ -147,6 +158,9 @@ ABI = {
     "psim_import_aos_device": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_device_soa": (c_int, [_P, POINTER(SoaView)]),
     "psim_checksum": (c_int, [_P, POINTER(c_uint64)]),
+    "psim_checkpoint_write": (c_int, [_P, c_char_p, c_uint64]),
+    "psim_checkpoint_read": (c_int, [_P, c_char_p, POINTER(c_uint64)]),
+    "psim_checkpoint_info": (c_int, [c_char_p, POINTER(CheckpointHeader)]),
     "psim_set_stream": (c_int, [_P, _P]),
     "psim_get_stream": (_P, [_P]),
     "psim_device": (c_int, [_P]),
@@ -369,6 +383,18 @@ class HipParticleSimulation:
         _check(self._lib.psim_checksum(self._h, out))
         return [int(v) for v in out]
 
+    # -- checkpoints
+    def save_checkpoint(self, path, step=0):
+        """Writes this handle's particles into the checkpoint file `path` (a shard writes
+        its own records of the whole-set file)."""
+        _check(self._lib.psim_checkpoint_write(self._h, os.fsencode(path), int(step)))
+
+    def load_checkpoint(self, path):
+        """Restores the particles from `path`; returns the stored step counter."""
+        step = c_uint64(0)
+        _check(self._lib.psim_checkpoint_read(self._h, os.fsencode(path), byref(step)))
+        return int(step.value)
+
     # -- streams
     def set_stream(self, hip_stream_ptr):
         _check(self._lib.psim_set_stream(self._h, c_void_p(hip_stream_ptr)))
@@ -440,6 +466,33 @@ def launch_shape(count, n_attractors=1):
     info = LaunchShapeInfo()
     _check(load_library().psim_launch_shape(count, n_attractors, byref(info)))
     return {name: getattr(info, name) for name, _ in LaunchShapeInfo._fields_}
+
+
+def checkpoint_info(path):
+    """Header fields of a checkpoint file (no device needed)."""
+    hdr = CheckpointHeader()
+    _check(load_library().psim_checkpoint_info(os.fsencode(path), byref(hdr)))
+    return {"version": hdr.version, "record_bytes": hdr.record_bytes,
+            "particle_count": hdr.particle_count, "step": hdr.step,
+            "generation_mode": hdr.generation_mode, "color_semantics": hdr.color_semantics}
+
+
+CHECKPOINT_HEADER_BYTES = 64
+
+
+def read_checkpoint_records(path, first=0, n=None):
+    """Particles [first, first + n) of a checkpoint file as a read-only PARTICLE_DTYPE
+    memory map (plain file access; for tools that inspect a checkpoint without a GPU)."""
+    info = checkpoint_info(path)
+    count = info["particle_count"]
+    if n is None:
+        n = count - first
+    if first < 0 or n < 0 or first + n > count:
+        raise ValueError(f"range [{first}, +{n}) exceeds the {count} particles of {path}")
+    if n == 0:
+        return np.empty(0, dtype=PARTICLE_DTYPE)
+    return np.memmap(path, dtype=PARTICLE_DTYPE, mode="r",
+                     offset=CHECKPOINT_HEADER_BYTES + first * PARTICLE_DTYPE.itemsize, shape=(n,))
 
 
 def version():

@@ -5,11 +5,15 @@
 // across the boundary.  There is no CPU fallback: without a gfx950 device
 // psim_create fails with PSIM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <new>
 #include <thread>
@@ -27,6 +31,7 @@ static_assert(offsetof(psim_particle, velocity) == 16, "layout");
 static_assert(offsetof(psim_particle, color) == 32, "layout");
 static_assert(offsetof(psim_particle, initial_color) == 48, "layout");
 static_assert(sizeof(psim_attractor) == 32, "attractor record is 32 bytes");
+static_assert(sizeof(psim_checkpoint_header) == 64, "checkpoint header is 64 bytes");
 
 #define PSIM_API extern "C" __attribute__((visibility("default")))
 
@@ -647,11 +652,14 @@ int ensure_bounce(psim_handle *h)
     return PSIM_OK;
 }
 
-// Download into pageable memory: the device copies slot after slot into two page-locked
-// bounce slots at the link rate while host threads move the previous slot into `dst`
-// (the runtime's own pageable path reaches 10.7 GB/s; this one is bound by the host copy).
-int download_aos_bounced(psim_handle *h, psim_particle *dst, uint64_t first, uint64_t n)
+// The way out through the bounce slots: the device copies slot after slot into the two
+// page-locked slots at the link rate while `drain(slot, offset, m)` -- called with
+// particles [offset, offset + m) of the request -- disposes of the previous one (a copy
+// into pageable memory, a file write).  `drain` returns a status code.
+template <typename Drain>
+int download_aos_through_slots(psim_handle *h, uint64_t first, uint64_t n, Drain drain)
 {
+    if (n == 0) return PSIM_OK;
     int rc = ensure_stage(h);
     if (rc != PSIM_OK) return rc;
     const uint64_t slot = kBounceParticles < h->stage_particles / 2 ? kBounceParticles
@@ -669,22 +677,26 @@ int download_aos_bounced(psim_handle *h, psim_particle *dst, uint64_t first, uin
         HIP_TRY(hipEventRecord(h->bounce_done[b], h->stream));
         if (c > 0) {                                   // the previous slot, while this one travels
             HIP_TRY(hipEventSynchronize(h->bounce_done[b ^ 1]));
-            parallel_memcpy(dst + prev_off, h->bounce + (uint64_t)(b ^ 1) * kBounceParticles,
-                            (size_t)prev_m * sizeof(psim_particle));
+            rc = drain(h->bounce + (uint64_t)(b ^ 1) * kBounceParticles, prev_off, prev_m);
+            if (rc != PSIM_OK) {
+                (void)hipStreamSynchronize(h->stream);
+                return rc;
+            }
         }
         prev_off = done, prev_m = m;
     }
     const int last = (int)((c - 1) & 1);
     HIP_TRY(hipEventSynchronize(h->bounce_done[last]));
-    parallel_memcpy(dst + prev_off, h->bounce + (uint64_t)last * kBounceParticles,
-                    (size_t)prev_m * sizeof(psim_particle));
-    return PSIM_OK;
+    return drain(h->bounce + (uint64_t)last * kBounceParticles, prev_off, prev_m);
 }
 
-// The way in from pageable memory, the same way round: host threads fill a page-locked slot
-// while the previous one travels to the device and is transposed there.
-int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first, uint64_t n)
+// The way in, the same way round: `fill(slot, offset, m)` fills a page-locked slot with
+// particles [offset, offset + m) of the request while the previous slot travels to the
+// device and is transposed there.
+template <typename Fill>
+int upload_aos_through_slots(psim_handle *h, uint64_t first, uint64_t n, Fill fill)
 {
+    if (n == 0) return PSIM_OK;
     int rc = ensure_stage(h);
     if (rc != PSIM_OK) return rc;
     const uint64_t slot = kBounceParticles < h->stage_particles / 2 ? kBounceParticles
@@ -697,7 +709,11 @@ int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first,
         const int b = (int)(c & 1);
         if (c >= 2) HIP_TRY(hipEventSynchronize(h->bounce_done[b]));      // slot consumed
         psim_particle *host = h->bounce + (uint64_t)b * kBounceParticles;
-        parallel_memcpy(host, src + done, (size_t)m * sizeof(psim_particle));
+        rc = fill(host, done, (uint64_t)m);
+        if (rc != PSIM_OK) {
+            (void)hipStreamSynchronize(h->stream);
+            return rc;
+        }
         HIP_TRY(hipMemcpyAsync(h->aos_stage + b * slot, host, (size_t)m * sizeof(psim_particle),
                                hipMemcpyHostToDevice, h->stream));
         HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)(first + done), m,
@@ -706,6 +722,26 @@ int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first,
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PSIM_OK;
+}
+
+// Pageable host memory on either side (the runtime's own pageable path reaches 10.7 GB/s
+// down; these are bound by the host copy).
+int download_aos_bounced(psim_handle *h, psim_particle *dst, uint64_t first, uint64_t n)
+{
+    return download_aos_through_slots(
+        h, first, n, [dst](const psim_particle *slot, uint64_t off, uint64_t m) {
+            parallel_memcpy(dst + off, slot, (size_t)m * sizeof(psim_particle));
+            return (int)PSIM_OK;
+        });
+}
+
+int upload_aos_bounced(psim_handle *h, const psim_particle *src, uint64_t first, uint64_t n)
+{
+    return upload_aos_through_slots(
+        h, first, n, [src](psim_particle *slot, uint64_t off, uint64_t m) {
+            parallel_memcpy(slot, src + off, (size_t)m * sizeof(psim_particle));
+            return (int)PSIM_OK;
+        });
 }
 
 // Plain device <-> pageable host copies (the SoA transfers) through the same two slots.
@@ -909,6 +945,151 @@ PSIM_API int psim_checksum(psim_handle *h, uint64_t out[6])
                            h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PSIM_OK;
+}
+
+// ---- checkpoints ----------------------------------------------------------------
+
+namespace {
+
+const char kCheckpointMagic[8] = {'P', 'S', 'I', 'M', 'C', 'K', 'P', '1'};
+
+struct File {
+    int fd = -1;
+    ~File()
+    {
+        if (fd >= 0) (void)close(fd);
+    }
+};
+
+int write_all(int fd, const void *buf, size_t bytes, uint64_t offset, const char *path)
+{
+    const char *p = static_cast<const char *>(buf);
+    while (bytes) {
+        const ssize_t w = pwrite(fd, p, bytes, (off_t)offset);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) return fail(PSIM_ERR_IO, "write to %s failed: %s", path, strerror(errno));
+        p += w, bytes -= (size_t)w, offset += (uint64_t)w;
+    }
+    return PSIM_OK;
+}
+
+int read_all(int fd, void *buf, size_t bytes, uint64_t offset, const char *path)
+{
+    char *p = static_cast<char *>(buf);
+    while (bytes) {
+        const ssize_t r = pread(fd, p, bytes, (off_t)offset);
+        if (r < 0 && errno == EINTR) continue;
+        if (r < 0) return fail(PSIM_ERR_IO, "read from %s failed: %s", path, strerror(errno));
+        if (r == 0) return fail(PSIM_ERR_IO, "%s is shorter than its header says", path);
+        p += r, bytes -= (size_t)r, offset += (uint64_t)r;
+    }
+    return PSIM_OK;
+}
+
+int read_header(int fd, const char *path, psim_checkpoint_header *out)
+{
+    struct stat st;
+    if (fstat(fd, &st) != 0) return fail(PSIM_ERR_IO, "stat of %s failed: %s", path, strerror(errno));
+    if ((uint64_t)st.st_size < sizeof(*out))
+        return fail(PSIM_ERR_IO, "%s is too short to be a checkpoint", path);
+    int rc = read_all(fd, out, sizeof(*out), 0, path);
+    if (rc != PSIM_OK) return rc;
+    if (memcmp(out->magic, kCheckpointMagic, sizeof(kCheckpointMagic)) != 0)
+        return fail(PSIM_ERR_IO, "%s is not a checkpoint (or its write was interrupted)", path);
+    if (out->version != 1u || out->record_bytes != sizeof(psim_particle))
+        return fail(PSIM_ERR_IO, "%s: unsupported checkpoint version %u / record size %u", path,
+                    out->version, out->record_bytes);
+    const uint64_t room = ((uint64_t)st.st_size - sizeof(*out)) / sizeof(psim_particle);
+    if (out->particle_count > room)
+        return fail(PSIM_ERR_IO, "%s holds %llu records, its header says %llu", path,
+                    (unsigned long long)room, (unsigned long long)out->particle_count);
+    return PSIM_OK;
+}
+
+uint64_t record_offset(uint64_t particle)
+{
+    return sizeof(psim_checkpoint_header) + particle * sizeof(psim_particle);
+}
+
+}  // namespace
+
+PSIM_API int psim_checkpoint_write(psim_handle *h, const char *path, uint64_t step)
+{
+    CHECK_HANDLE(h);
+    if (!path) return fail(PSIM_ERR_INVALID, "null path");
+    File f;
+    f.fd = open(path, O_WRONLY | O_CREAT | O_CLOEXEC, 0644);
+    if (f.fd < 0) return fail(PSIM_ERR_IO, "cannot open %s for writing: %s", path, strerror(errno));
+    const bool shard = h->global_count != 0;
+    const uint64_t total = shard ? h->global_count : (uint64_t)h->count;
+    const uint64_t first = h->global_first;
+    psim_checkpoint_header hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    int rc = PSIM_OK;
+    if (!shard) {                                   // no valid header while the records change
+        rc = write_all(f.fd, &hdr, sizeof(hdr), 0, path);
+        if (rc != PSIM_OK) return rc;
+    }
+    const int fd = f.fd;
+    rc = download_aos_through_slots(
+        h, 0, h->count, [fd, first, path](const psim_particle *slot, uint64_t off, uint64_t m) {
+            return write_all(fd, slot, (size_t)m * sizeof(psim_particle), record_offset(first + off),
+                             path);
+        });
+    if (rc != PSIM_OK) return rc;
+    if (first + h->count == total && ftruncate(f.fd, (off_t)record_offset(total)) != 0)
+        return fail(PSIM_ERR_IO, "cannot size %s: %s", path, strerror(errno));
+    if (first == 0) {
+        memcpy(hdr.magic, kCheckpointMagic, sizeof(kCheckpointMagic));
+        hdr.version = 1;
+        hdr.record_bytes = sizeof(psim_particle);
+        hdr.particle_count = total;
+        hdr.step = step;
+        hdr.generation_mode = (uint32_t)h->generation_mode;
+        hdr.color_semantics = (uint32_t)h->colour_semantics;
+        rc = write_all(f.fd, &hdr, sizeof(hdr), 0, path);
+        if (rc != PSIM_OK) return rc;
+    }
+    const int cfd = f.fd;
+    f.fd = -1;
+    if (close(cfd) != 0) return fail(PSIM_ERR_IO, "closing %s failed: %s", path, strerror(errno));
+    return PSIM_OK;
+}
+
+PSIM_API int psim_checkpoint_read(psim_handle *h, const char *path, uint64_t *step_out)
+{
+    CHECK_HANDLE(h);
+    if (!path) return fail(PSIM_ERR_INVALID, "null path");
+    File f;
+    f.fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (f.fd < 0) return fail(PSIM_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    psim_checkpoint_header hdr;
+    int rc = read_header(f.fd, path, &hdr);
+    if (rc != PSIM_OK) return rc;
+    const uint64_t total = h->global_count ? h->global_count : (uint64_t)h->count;
+    if (hdr.particle_count != total)
+        return fail(PSIM_ERR_INVALID, "%s holds %llu particles, the simulation %llu", path,
+                    (unsigned long long)hdr.particle_count, (unsigned long long)total);
+    const int fd = f.fd;
+    const uint64_t first = h->global_first;
+    h->colours_changed = true;                   // the file's colours, whatever they are
+    rc = upload_aos_through_slots(
+        h, 0, h->count, [fd, first, path](psim_particle *slot, uint64_t off, uint64_t m) {
+            return read_all(fd, slot, (size_t)m * sizeof(psim_particle), record_offset(first + off),
+                            path);
+        });
+    if (rc != PSIM_OK) return rc;
+    if (step_out) *step_out = hdr.step;
+    return PSIM_OK;
+}
+
+PSIM_API int psim_checkpoint_info(const char *path, psim_checkpoint_header *out)
+{
+    if (!path || !out) return fail(PSIM_ERR_INVALID, "null argument");
+    File f;
+    f.fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (f.fd < 0) return fail(PSIM_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    return read_header(f.fd, path, out);
 }
 
 // ---- streams ------------------------------------------------------------------
