@@ -5,12 +5,14 @@
 //
 // Built with a plain host compiler against include/psim.hpp + libpsim_hip.so.
 // It records the SimParams it used, frame by frame, and the final particles, so the
-// test-suite can replay the same stream through the CPU oracle.
+// test-suite can replay the same stream through the CPU oracle.  Half way through, the
+// state takes a detour through a checkpoint file.
 //
 // usage: frame_loop <count> <generation 0|1|2> <frames> <params_out> <particles_out>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "psim.hpp"
@@ -57,6 +59,16 @@ int main(int argc, char **argv)
             if (frame == 60) color_mode = 0;
             if (frame == 44) sim.set_paused(true);             // pause button (app.rs:346-348)
             if (frame == 48) sim.set_paused(false);
+
+            if (frame == frames / 2) {
+                // stop and resume: the state goes to a file, the simulation is reset, the
+                // file comes back -- the run must end exactly where it would have anyway
+                const std::string ckp = std::string(argv[5]) + ".ckp";
+                sim.save_checkpoint(ckp, static_cast<uint64_t>(frame));
+                sim.reset(psim::SphereGeneration::Uniform);
+                if (sim.load_checkpoint(ckp) != static_cast<uint64_t>(frame)) return 6;
+                std::remove(ckp.c_str());
+            }
 
             if (!sim.is_paused()) {                            // app.rs:283
                 psim::SimParams p = psim::default_sim_params();
