@@ -152,7 +152,9 @@ void psim_destroy(psim_handle *h);
  * reference's compute backend (src/simulation/compute.rs:124-144): the kernel is
  * enqueued on the handle's stream and the call returns; `*params` is copied
  * before returning.  Like the reference, the paused flag is NOT consulted here
- * (the caller gates on is_paused, src/app.rs:283). */
+ * (the caller gates on is_paused, src/app.rs:283).  The call only enqueues kernels whose
+ * arguments travel by value, so it may be made while the handle's stream (psim_set_stream)
+ * is being captured into a HIP graph; replaying the graph repeats the recorded steps. */
 int psim_update(psim_handle *h, const psim_sim_params *params);
 
 /* Multi-attractor step: gravity, then for a = 0..n_attractors-1 in index order
