@@ -154,7 +154,9 @@ void psim_destroy(psim_handle *h);
  * before returning.  Like the reference, the paused flag is NOT consulted here
  * (the caller gates on is_paused, src/app.rs:283).  The call only enqueues kernels whose
  * arguments travel by value, so it may be made while the handle's stream (psim_set_stream)
- * is being captured into a HIP graph; replaying the graph repeats the recorded steps. */
+ * is being captured into a HIP graph; replaying the graph repeats the recorded steps.
+ * (Under PSIM_COLOR_RESET the colour copy is decided when the call is made, that is at
+ * capture: capture the steps of a graph in the colour state they will be replayed in.) */
 int psim_update(psim_handle *h, const psim_sim_params *params);
 
 /* Multi-attractor step: gravity, then for a = 0..n_attractors-1 in index order
