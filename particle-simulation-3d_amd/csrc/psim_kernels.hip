@@ -131,8 +131,178 @@ __device__ __forceinline__ void attract(float &vx, float &vy, float &vz, float p
     }
 }
 
+template <int N>
+__device__ __forceinline__ void apply_gravity(float (&vy)[N], const psim_sim_params &p)
+{
+    const float gdt = p.gravity * p.delta_time;
+#pragma unroll
+    for (int j = 0; j < N; ++j) vy[j] = vy[j] - gdt;         // cpu.rs:72
+}
+
+template <int N>
+__device__ __forceinline__ void integrate(float (&px)[N], float (&py)[N], float (&pz)[N],
+                                          float (&vx)[N], float (&vy)[N], float (&vz)[N],
+                                          const psim_sim_params &p)
+{
+    const float dt = p.delta_time;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        px[j] = px[j] + vx[j] * dt;                          // cpu.rs:87
+        py[j] = py[j] + vy[j] * dt;
+        pz[j] = pz[j] + vz[j] * dt;
+        vx[j] = vx[j] * p.damping;                           // cpu.rs:90
+        vy[j] = vy[j] * p.damping;
+        vz[j] = vz[j] * p.damping;
+    }
+}
+
+// ---- attractor lists through a per-wave queue of in-range pairs -------------------
+//
+// With a list, the in-range test (9 VALU instructions per particle and attractor) is cheap
+// and the force law behind it (a square root, two divisions: ~60 instructions) is dear.  With
+// r = 10 in the 100-unit cube only 1.9 % of the particles are in range of an attractor, yet
+// 71 % of the 64-lane wave instructions of the straightforward loop run the force law for
+// at least one lane.  Here a wave first tests its 256 particles against a chunk of
+// PSIM_PAIR_CHUNK attractors, remembering hits as bit masks; the lanes then write their hits
+// one after the other into a queue in LDS (positions from a wave-wide prefix sum), the
+// wave works the queue off with every lane busy, and each lane adds the resulting velocity
+// terms to its particles in attractor order.  The force on a particle depends on positions
+// only, which do not change before all attractors are applied, so every term has the value
+// the loop would compute; the additions happen in the same order; the result is the same
+// bit for bit.  A chunk with more hits than the queue holds (large radii) takes the loop.
+#define PSIM_PAIR_CHUNK 16u     /* attractors tested per round: the hit mask of a particle */
+#define PSIM_PAIR_QUEUE 256u    /* in-range (particle, attractor) pairs a wave queues per round */
+
+// Exclusive prefix sum of `x` over the 64 lanes (all active); `total` = the wave's sum, in
+// a scalar register.  Seven data-parallel-primitive adds (row shifts, then the two row
+// broadcasts of the gfx9 family); no LDS traffic.
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t x, uint32_t &total)
+{
+    // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes that are masked
+    // out or whose source lies outside the row keep `old` = 0.
+#define PSIM_DPP(src, ctrl, rows, banks) \
+    (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(src), ctrl, rows, banks, false)
+    uint32_t v = x + PSIM_DPP(x, 0x111, 0xF, 0xF);           // row_shr:1
+    v += PSIM_DPP(x, 0x112, 0xF, 0xF);                       // row_shr:2
+    v += PSIM_DPP(x, 0x113, 0xF, 0xF);                       // row_shr:3  -> sums of 4 within a row
+    v += PSIM_DPP(v, 0x114, 0xF, 0xE);                       // row_shr:4, banks 1-3
+    v += PSIM_DPP(v, 0x118, 0xF, 0xC);                       // row_shr:8, banks 2-3 -> rows done
+    v += PSIM_DPP(v, 0x142, 0xA, 0xF);                       // row_bcast:15 into rows 1 and 3
+    v += PSIM_DPP(v, 0x143, 0xC, 0xF);                       // row_bcast:31 into rows 2 and 3
+#undef PSIM_DPP
+    total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return v - x;
+}
+
+// Orders one wave's LDS writes before its LDS reads that follow (LDS operations of a wave
+// execute in order; this pins the compiler's ordering).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The attractor loop of step<2, 4> for a whole wave (every lane must call; lanes without
+// particles pass live = false).  `alist` is the list in LDS with thresholds in _pad[0],
+// `queue` the wave's PSIM_PAIR_QUEUE quads of LDS.
+__device__ __forceinline__ void attract_list_queued(float (&px)[4], float (&py)[4], float (&pz)[4],
+                                                    float (&vx)[4], float (&vy)[4], float (&vz)[4],
+                                                    const psim_attractor *alist, uint32_t na,
+                                                    float dt, f32x4 *queue, uint32_t lane,
+                                                    bool live)
+{
+    for (uint32_t c0 = 0; c0 < na; c0 += PSIM_PAIR_CHUNK) {
+        const uint32_t cn = (na - c0) < PSIM_PAIR_CHUNK ? (na - c0) : PSIM_PAIR_CHUNK;
+        uint32_t mask[4] = {0u, 0u, 0u, 0u};
+        const auto test = [&](uint32_t a) {                  // hits of attractor c0 + a
+            const psim_attractor &at = alist[c0 + a];
+            if (at.active > 0) {
+                const float thr = __uint_as_float(at._pad[0]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dx = at.position[0] - px[j], dy = at.position[1] - py[j],
+                                dz = at.position[2] - pz[j];
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const uint32_t in = (live && d2 < thr) ? 1u : 0u;     // cpu.rs:79
+                    mask[j] |= in << a;
+                }
+            }
+        };
+        // The chunk's first attractor alone tells (nearly for free: four scalar population
+        // counts) whether the chunk is likely to overflow the queue, as large radii do;
+        // the other tests are then not spent.  A wrong guess costs time, not correctness.
+        test(0);
+        uint32_t first_hits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            first_hits += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mask[j] & 1u));
+        uint32_t total = PSIM_PAIR_QUEUE + 1u, base = 0;
+        if (first_hits * cn <= PSIM_PAIR_QUEUE) {
+            for (uint32_t a = 1; a < cn; ++a) test(a);
+            const uint32_t hits =
+                (uint32_t)(__builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
+                           __builtin_popcount(mask[2]) + __builtin_popcount(mask[3]));
+            base = wave_exclusive_scan(hits, total);
+            if (total == 0) continue;
+        }
+        if (total > PSIM_PAIR_QUEUE) {                       // too many for the queue: the loop
+            for (uint32_t a = 0; a < cn; ++a) {
+                const psim_attractor at = alist[c0 + a];
+                if (at.active > 0) {
+                    const float two_r = at.radius * 2.0f;
+                    const float thr = __uint_as_float(at._pad[0]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (live)
+                            attract(vx[j], vy[j], vz[j], px[j], py[j], pz[j], at.position[0],
+                                    at.position[1], at.position[2], at.force, two_r, thr, dt);
+                }
+            }
+            continue;
+        }
+        // the lane's hits, particle by particle and in attractor order, at base, base + 1, ...
+        uint32_t k = base;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (uint32_t m = mask[j]; m; m &= m - 1u)
+                queue[k++] = f32x4{px[j], py[j], pz[j],
+                                   __uint_as_float(c0 + (uint32_t)__builtin_ctz(m))};
+        wave_lds_sync();
+        for (uint32_t q = lane; q < total; q += 64u) {      // cpu.rs:76-82 of one pair per lane
+            const f32x4 e = queue[q];
+            const psim_attractor &at = alist[__float_as_uint(e[3])];
+            const float two_r = at.radius * 2.0f;
+            const float dx = at.position[0] - e[0], dy = at.position[1] - e[1],
+                        dz = at.position[2] - e[2];
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const float dist = sqrtf(d2);
+            const float t = 1.0f - dist / two_r;
+            const float ff = (t * t) * 2.0f;
+            const float inv = 1.0f / dist;
+            const float fx = ((dx * inv) * at.force) * ff;
+            const float fy = ((dy * inv) * at.force) * ff;
+            const float fz = ((dz * inv) * at.force) * ff;
+            queue[q] = f32x4{fx * dt, fy * dt, fz * dt, 0.0f};
+        }
+        wave_lds_sync();
+        k = base;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (uint32_t m = mask[j]; m; m &= m - 1u) {
+                const f32x4 term = queue[k++];
+                vx[j] = vx[j] + term[0];                     // cpu.rs:82
+                vy[j] = vy[j] + term[1];
+                vz[j] = vz[j] + term[2];
+            }
+        wave_lds_sync();                                     // the next round rewrites the queue
+    }
+}
+
 // FORCE: 0 = no attractor, 1 = the single attractor of SimParams,
-//        2 = attractor list in LDS, 3 = attractor list in kernel arguments.
+//        2 = attractor list in LDS, 3 = attractor list in kernel arguments,
+//        4 = attractor list in LDS, worked off through the queue of in-range pairs
+//            (attract_list_queued; step<4, N> itself is the loop of 2, for the tail).
 //
 // Steps N particles held in registers.  Particles are independent, so for a list the
 // attractor loop is the OUTER loop: each attractor record is fetched once per N
@@ -145,9 +315,7 @@ __device__ __forceinline__ void step(float (&px)[N], float (&py)[N], float (&pz)
                                      uint32_t na)
 {
     const float dt = p.delta_time;
-    const float gdt = p.gravity * dt;
-#pragma unroll
-    for (int j = 0; j < N; ++j) vy[j] = vy[j] - gdt;         // cpu.rs:72
+    apply_gravity<N>(vy, p);
     // The in-range threshold of each attractor rides in a padding word of the kernel's own
     // copy of the record (SimParams::_padding2, psim_attractor::_pad[0]); see with_threshold().
     if constexpr (FORCE == 1) {
@@ -170,15 +338,7 @@ __device__ __forceinline__ void step(float (&px)[N], float (&py)[N], float (&pz)
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        px[j] = px[j] + vx[j] * dt;                          // cpu.rs:87
-        py[j] = py[j] + vy[j] * dt;
-        pz[j] = pz[j] + vz[j] * dt;
-        vx[j] = vx[j] * p.damping;                           // cpu.rs:90
-        vy[j] = vy[j] * p.damping;
-        vz[j] = vz[j] * p.damping;
-    }
+    integrate<N>(px, py, pz, vx, vy, vz, p);
 }
 
 // Colour of one particle for modes 1 and 2 (cpu.rs:93-105), from the damped
@@ -275,13 +435,16 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
 {
     constexpr bool NT = MODE == PSIM_ACCESS_STREAM;          // non-temporal loads
     const psim_attractor *alist = nullptr;
-    if constexpr (FORCE == 2) {
-        // Stage the attractor list (<= 2 KiB) into LDS once per workgroup.
+    if constexpr (FORCE == 2 || FORCE == 4) {
+        // Stage the attractor list (<= 2 KiB) into LDS once per workgroup; the queued form
+        // also takes a list that came in the kernel arguments (attr_dev == nullptr).
         __shared__ psim_attractor lds_attr[PSIM_MAX_ATTRACTORS];
         const uint32_t words = na * (sizeof(psim_attractor) / 4u);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(attr_dev);
+        if constexpr (FORCE == 4)
+            if (!attr_dev) src = reinterpret_cast<const uint32_t *>(ka.a);
         for (uint32_t w = threadIdx.x; w < words; w += PSIM_UPDATE_BLOCK)
-            reinterpret_cast<uint32_t *>(lds_attr)[w] =
-                reinterpret_cast<const uint32_t *>(attr_dev)[w];
+            reinterpret_cast<uint32_t *>(lds_attr)[w] = src[w];
         __syncthreads();
         static_assert(PSIM_MAX_ATTRACTORS <= PSIM_UPDATE_BLOCK, "one lane per attractor");
         if (threadIdx.x < na)                                 // one lane per attractor
@@ -308,7 +471,40 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
         const uint32_t g = g0 + lane;
         const bool live = g < ngroups;
         f32x4 col[4];
-        if (live) {
+        if constexpr (FORCE == 4) {
+            // The queued list needs the whole wave in step: lanes past the end carry zeros.
+            __shared__ f32x4 queue[PSIM_UPDATE_BLOCK / 64][PSIM_PAIR_QUEUE];
+            f32x4 x = {}, y = {}, z = {}, u = {}, v = {}, w = {};
+            if (live) {
+                x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
+                u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
+            }
+            float a[4], b[4], c[4], d[4], e[4], f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = x[j]; b[j] = y[j]; c[j] = z[j];
+                d[j] = u[j]; e[j] = v[j]; f[j] = w[j];
+            }
+            apply_gravity<4>(e, p);
+            attract_list_queued(a, b, c, d, e, f, alist, na, p.delta_time,
+                                queue[threadIdx.x >> 6], lane, live);
+            integrate<4>(a, b, c, d, e, f, p);
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
+                    u[j] = d[j]; v[j] = e[j]; w[j] = f[j];
+                }
+                st_state<MODE>(px4, g0, ngroups, lane, x); st_state<MODE>(py4, g0, ngroups, lane, y);
+                st_state<MODE>(pz4, g0, ngroups, lane, z); st_state<MODE>(vx4, g0, ngroups, lane, u);
+                st_state<MODE>(vy4, g0, ngroups, lane, v); st_state<MODE>(vz4, g0, ngroups, lane, w);
+                if constexpr (CM != 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        col[j] = colour<CM>(a[j], b[j], c[j], d[j], e[j], f[j], p);
+                }
+            }
+        } else if (live) {
             f32x4 x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
             f32x4 u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
             float a[4], b[4], c[4], d[4], e[4], f[4];
@@ -527,7 +723,8 @@ static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params 
     // limit how many workgroups a CU holds at once (see choose_tuning()).
     // The reservation counts the LDS the kernel itself declares.
     constexpr uint32_t used = (CM != 0 ? (PSIM_UPDATE_BLOCK / 64) * 4 * PSIM_COLOUR_ROW * 16 : 0) +
-                              (FORCE == 2 ? PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) : 0);
+                              (FORCE == 2 || FORCE == 4 ? PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) : 0) +
+                              (FORCE == 4 ? (PSIM_UPDATE_BLOCK / 64) * PSIM_PAIR_QUEUE * 16 : 0);
     uint32_t want = CM != 0 ? t.reserve_lds_colour : t.reserve_lds;
     // A list of one attractor carries the loop of the list kernels: 7 workgroups per CU
     // (0.741 ms at 100 M particles) rather than the 6 of the plain kernel (0.783 ms).
@@ -613,12 +810,29 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     // band: 7 (6.57-6.61 k against 6.28-6.48 k for 6).
     t.reserve_lds = cap ? ((stream || resident) ? 26624u : 23040u) : 0u;
     t.reserve_lds_colour = t.reserve_lds;
-    // Streaming with a list of 2-4 attractors: 13 workgroups per CU (ms per step at 100 M
-    // particles, 2 / 4 attractors: 13 resident 0.752 / 0.766, 7 resident 0.854 / 1.05,
-    // 10 resident 0.769 / 0.889, uncapped 0.828 / 0.820).
-    if (state_bytes >= 96000000ull && n_attractors >= 2 && n_attractors <= 4)
-        t.reserve_lds = t.reserve_lds_colour = 11776u;
+    // A list of 2-5 attractors (worked off through the pair queue): 13 workgroups per CU
+    // (ms per step at 100 M particles, 2 / 4 / 5 attractors: 13 resident 0.759 / 0.758 /
+    // 0.760, 7 resident 1.01 / 1.06 / 1.07, 10 resident 0.843 / 0.864 / 0.877, uncapped
+    // 0.759 / 0.751 / 0.794); from 6 attractors on no cap (8 / 16 / 64 attractors: 0.768 /
+    // 0.899 / 2.40 uncapped, 0.830 / 1.14 / 3.25 with 13 resident).
+    // States that do not stream run lists uncapped (6.25 M particles, 2 / 8 / 64 attractors,
+    // us per step: 44 / 48 / 178 uncapped, 46 / 54 / 228 with 13 resident; 8 attractors
+    // without the queue: 74).
+    if (n_attractors >= 2)
+        t.reserve_lds = t.reserve_lds_colour = (stream && n_attractors <= 5) ? 11776u : 0u;
     return t;
+}
+
+// Experiments only: PSIM_QUEUE_FROM overrides the list length from which the queued form
+// is used (0 = never).
+static uint32_t queue_from()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("PSIM_QUEUE_FROM");
+        const int x = e && *e ? atoi(e) : 2;
+        return x <= 0 ? 0xFFFFFFFFu : (uint32_t)x;
+    }();
+    return v;
 }
 
 hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &params, int force,
@@ -632,6 +846,12 @@ hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &pa
     if (force == 3)
         for (uint32_t a = 0; a < na; ++a) ka.a[a] = with_threshold(attr_host[a]);
     const uint32_t grid = update_grid(n, t);
+    // Lists of two attractors and more go through the queue of in-range pairs (100 M
+    // particles, r = 10, ms per step with / without: 2 attractors in device memory 0.759 /
+    // 0.811, 4: 0.751 / 0.858, 8: 0.768 / 1.00, 16: 0.899 / 1.96, 64: 2.40 / 7.59; lists that
+    // came in the kernel arguments: 2-4 attractors equal, 8: 0.761 / 0.947).
+    if (force >= 2 && na >= queue_from())
+        return launch_cm<4>(s, n, p, force == 2 ? attr_dev : nullptr, na, ka, t, grid, stream);
     switch (force) {
     case 0: return launch_cm<0>(s, n, p, nullptr, 0, ka, t, grid, stream);
     case 1: return launch_cm<1>(s, n, p, nullptr, 0, ka, t, grid, stream);

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Attractor-list update at a given size: ms per step for list lengths A, under the
+environment's launch overrides (PSIM_QUEUE_FROM, PSIM_RESERVE_LDS, PSIM_NT); one child
+process per setting because the overrides are read once per process.
+
+usage: exp_lists.py particles A[,A...] radius [NAME=value,... ; NAME=value,... ; ...]"""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(n, lengths, radius):
+    sys.path.insert(0, ROOT)
+    psim = importlib.import_module("particle-simulation-3d_amd")
+    params = psim.SimParams(delta_time=0.016, gravity=0.0, color_mode=0, damping=0.99)
+    sim = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
+    scratch = psim.HipParticleSimulation.new(4096, psim.GEN_UNIFORM)
+    buf = scratch.get_particle_buffer().color
+    rng = np.random.default_rng(1)
+    out = []
+    for a_count in lengths:
+        attrs = np.zeros(a_count, dtype=psim.ATTRACTOR_DTYPE)
+        attrs["position"] = rng.uniform(-40, 40, size=(a_count, 3)).astype(np.float32)
+        attrs["force"], attrs["radius"], attrs["active"] = 5.0, radius, 1
+        for i in range(a_count):
+            sim.store_attractor(buf + 32 * i, attrs[i:i + 1])
+        best = 1e9
+        for _ in range(3):
+            sim.update_multi_device(params, buf, a_count)
+            sim.sync()
+            sim.timer_start()
+            for _ in range(10):
+                sim.update_multi_device(params, buf, a_count)
+            best = min(best, sim.timer_stop() / 10)
+        out.append(f"A={a_count}: {best:7.4f} ms")
+    tag = " ".join(f"{k}={os.environ[k]}" for k in ("PSIM_QUEUE_FROM", "PSIM_RESERVE_LDS", "PSIM_NT")
+                   if k in os.environ) or "defaults"
+    print(f"{n} particles r={radius} [{tag}]  " + "  ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "child":
+        child(int(sys.argv[2]), [int(x) for x in sys.argv[3].split(",")], float(sys.argv[4]))
+    else:
+        settings = sys.argv[4].split(";") if len(sys.argv) > 4 else [""]
+        for setting in settings:
+            env = dict(os.environ)
+            for pair in filter(None, (x.strip() for x in setting.split(","))):
+                k, v = pair.split("=")
+                env[k] = v
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child", *sys.argv[1:4]],
+                           env=env, check=True, timeout=300)

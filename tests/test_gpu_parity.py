@@ -184,6 +184,49 @@ def test_multi_attractor_device_list(k):
     T.assert_particles_equal(got, want, f"{k} attractors (device list)")
 
 
+@pytest.mark.parametrize("k,radius", [(5, 3.0), (8, 10.0), (16, 8.0), (17, 8.0), (33, 6.0),
+                                      (64, 10.0), (64, 2.0), (12, 22.0), (40, None)])
+def test_long_lists_through_the_pair_queue(k, radius):
+    """Lists of five attractors and more are worked off through the per-wave queue of
+    in-range pairs.  Small radii leave the queue partly filled, r = 22 overflows it in most
+    rounds (the loop takes over), None mixes tiny, huge, zero, NaN and inactive entries;
+    17 / 33 / 40 / 64 attractors span several 16-attractor rounds.  A particle sits exactly
+    on an attractor (0/0 -> NaN must come out as in the oracle), another shares two
+    attractors' ranges (two terms added in list order)."""
+    rng = np.random.default_rng(7000 + k)
+    attrs = _attractors(rng, k)
+    if radius is None:
+        attrs["radius"] = rng.choice(np.array([0.0, 0.5, 3.0, 9.0, 60.0, np.nan], np.float32), k)
+        attrs["active"] = rng.integers(0, 2, k)
+        attrs["active"][0] = 1
+    else:
+        attrs["radius"] = np.float32(radius)
+    r0 = float(attrs["radius"][0])
+    attrs["position"][1] = attrs["position"][0] + np.float32(0.75 * r0 if r0 > 0 else 1.0)
+    params = T.bench_params(gravity=0.25, delta_time=0.01)
+    n = 70_003                                           # the last wave is partial
+    with Sim.new(n, psim.GEN_UNIFORM) as sim, Sim.new(4096, psim.GEN_UNIFORM) as scratch:
+        start = sim.download_aos()
+        start["position"][12345] = attrs["position"][0]              # dist == 0
+        start["position"][n - 2] = attrs["position"][0] + np.float32(0.25)
+        sim.upload_aos(start)
+        buf = scratch.get_particle_buffer().color
+        for i in range(k):
+            sim.store_attractor(buf + 32 * i, attrs[i:i + 1])
+        for _ in range(3):
+            sim.update_multi_device(params, buf, k)
+        got = sim.download_aos()
+        if k <= 8:                                       # the same list from host memory
+            with Sim.new(n, psim.GEN_UNIFORM) as host_list:
+                host_list.upload_aos(start)
+                for _ in range(3):
+                    host_list.update_multi(params, attrs)
+                assert host_list.download_aos().tobytes() == got.tobytes()
+    want = T.oracle_update_aos(start, params, 3, attrs)
+    T.assert_particles_equal(got, want, f"{k} attractors, radius {radius}")
+    assert np.isnan(got["velocity"][12345]).any() == np.isnan(want["velocity"][12345]).any()
+
+
 def test_single_attractor_list_equals_update():
     params = T.bench_params(mouse_radius=30.0, mouse_force=40.0)
     one = np.zeros(1, dtype=psim.ATTRACTOR_DTYPE)

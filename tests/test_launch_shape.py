@@ -34,11 +34,13 @@ def test_single_attractor_shape_by_size(count, access, reserve):
 def test_attractor_lists():
     for n in (6_250_000, 100_000_000):
         assert psim.launch_shape(n, 1)["reserve_lds"] == 26624
-        for a in (2, 3, 4):                                    # 13 workgroups per CU
-            s = psim.launch_shape(n, a)
-            assert s["reserve_lds"] == 11776 and s["resident_per_cu"] == 13
-        for a in (5, 8, 64):                                   # VALU-bound: no cap
-            assert psim.launch_shape(n, a)["reserve_lds"] == 0
+    for a in (2, 3, 4, 5):                                     # streaming: 13 workgroups per CU
+        s = psim.launch_shape(100_000_000, a)
+        assert s["reserve_lds"] == 11776 and s["resident_per_cu"] == 13
+        assert psim.launch_shape(6_250_000, a)["reserve_lds"] == 0     # cache-resident: no cap
+    for a in (6, 8, 64):                                       # longer lists: no cap anywhere
+        assert psim.launch_shape(100_000_000, a)["reserve_lds"] == 0
+        assert psim.launch_shape(6_250_000, a)["reserve_lds"] == 0
     assert psim.launch_shape(100_000, 8)["reserve_lds"] == 0
 
 
