@@ -726,9 +726,13 @@ static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params 
                               (FORCE == 2 || FORCE == 4 ? PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) : 0) +
                               (FORCE == 4 ? (PSIM_UPDATE_BLOCK / 64) * PSIM_PAIR_QUEUE * 16 : 0);
     uint32_t want = CM != 0 ? t.reserve_lds_colour : t.reserve_lds;
-    // A list of one attractor carries the loop of the list kernels: 7 workgroups per CU
-    // (0.741 ms at 100 M particles) rather than the 6 of the plain kernel (0.783 ms).
-    if (FORCE >= 2 && want == 26624u) want = 23040u;
+    // A list of one attractor in the kernel arguments carries the loop of the list kernels:
+    // 7 workgroups per CU (0.741 ms at 100 M particles) rather than the 6 of the plain
+    // kernel (0.783 ms).  The kernels that stage a list into LDS start with a barrier and
+    // want at least 13 (one attractor, 100 M particles: 0.751 ms against 0.951 with 7;
+    // 6.25 M: 43 us against 49).
+    if (FORCE == 3 && want == 26624u) want = 23040u;
+    if ((FORCE == 2 || FORCE == 4) && want > 11776u) want = 11776u;
     const uint32_t extra = want > used ? want - used : 0;
     switch (t.access) {
     case PSIM_ACCESS_STREAM:
@@ -850,7 +854,10 @@ hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &pa
     // particles, r = 10, ms per step with / without: 2 attractors in device memory 0.759 /
     // 0.811, 4: 0.751 / 0.858, 8: 0.768 / 1.00, 16: 0.899 / 1.96, 64: 2.40 / 7.59; lists that
     // came in the kernel arguments: 2-4 attractors equal, 8: 0.761 / 0.947).
-    if (force >= 2 && na >= queue_from())
+    // A list in device memory is staged into LDS anyway and takes the queue from one
+    // attractor on.
+    const uint32_t from = queue_from();
+    if (force >= 2 && na >= 1 && from != 0xFFFFFFFFu && (force == 2 || na >= from))
         return launch_cm<4>(s, n, p, force == 2 ? attr_dev : nullptr, na, ka, t, grid, stream);
     switch (force) {
     case 0: return launch_cm<0>(s, n, p, nullptr, 0, ka, t, grid, stream);
