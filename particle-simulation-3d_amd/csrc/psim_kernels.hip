@@ -219,13 +219,19 @@ __device__ __forceinline__ void attract_list_queued(float (&px)[4], float (&py)[
             const psim_attractor &at = alist[c0 + a];
             if (at.active > 0) {
                 const float thr = __uint_as_float(at._pad[0]);
+                // two particles per packed fp32 instruction (each lane of a packed operation
+                // rounds like the scalar one; nothing is fused)
+                const f32x2 ax = {at.position[0], at.position[0]},
+                            ay = {at.position[1], at.position[1]},
+                            az = {at.position[2], at.position[2]};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float dx = at.position[0] - px[j], dy = at.position[1] - py[j],
-                                dz = at.position[2] - pz[j];
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;
-                    const uint32_t in = (live && d2 < thr) ? 1u : 0u;     // cpu.rs:79
-                    mask[j] |= in << a;
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 dx = ax - f32x2{px[2 * h], px[2 * h + 1]},
+                                dy = ay - f32x2{py[2 * h], py[2 * h + 1]},
+                                dz = az - f32x2{pz[2 * h], pz[2 * h + 1]};
+                    const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+                    mask[2 * h] |= ((live && d2[0] < thr) ? 1u : 0u) << a;       // cpu.rs:79
+                    mask[2 * h + 1] |= ((live && d2[1] < thr) ? 1u : 0u) << a;
                 }
             }
         };
