@@ -116,6 +116,41 @@ def test_hundred_million_particles_checksum_and_slices():
     assert gpu_sum == want_sum
 
 
+def test_hundred_million_particles_with_attractor_lists():
+    """The streaming launch shape of the list kernel (pair queue) at full size: 8 attractors
+    of r = 10 and 40 of mixed radii, whole state compared through the checksum."""
+    n = 100_000_000
+    rng = np.random.default_rng(2024)
+    lists = []
+    for k, radii in ((8, [10.0]), (40, [2.0, 6.0, 10.0, 30.0])):
+        a = np.zeros(k, dtype=psim.ATTRACTOR_DTYPE)
+        a["position"] = rng.uniform(-45, 45, size=(k, 3)).astype(np.float32)
+        a["force"] = rng.uniform(1, 60, size=k).astype(np.float32)
+        a["radius"] = rng.choice(np.array(radii, np.float32), k)
+        a["active"] = 1
+        lists.append(a)
+    params = T.bench_params(gravity=0.5)
+    with Sim.new(n, psim.GEN_UNIFORM) as sim, Sim.new(4096, psim.GEN_UNIFORM) as scratch:
+        buf = scratch.get_particle_buffer().color
+        for a in lists:
+            for i in range(len(a)):
+                sim.store_attractor(buf + 32 * i, a[i:i + 1])
+            sim.update_multi_device(params, buf, len(a))
+            sim.sync()
+        gpu_sum = sim.checksum()
+        tail = sim.download_soa(n - 4099, 4099)
+    want_sum = [0] * 6
+    chunk = 25_000_000
+    for f in range(0, n, chunk):
+        w = T.oracle_gen_uniform_soa(f, chunk)
+        for a in lists:
+            w, _ = T.oracle_update_soa(w, params, 1, attractors=a)
+        want_sum = [(x + y) % (1 << 64) for x, y in zip(want_sum, T.oracle_checksum_soa(w))]
+        if f + chunk == n:
+            T.assert_same_f32(tail, w[:, -4099:], "last particles")
+    assert gpu_sum == want_sum
+
+
 def test_more_than_two_to_the_31_particles():
     """Maximum-size edge: 2.2 G particles (141 GB of the 288 GB HBM) in one handle, past
     every 31-bit index.  Slices at the start, across 2^31 and at the end must match the
