@@ -111,32 +111,50 @@ __device__ __forceinline__ float length3(float x, float y, float z)
 // Force law of one attractor, cpu.rs:76-83.  `two_r` is radius * 2.0, `thr` =
 // psim_in_range_threshold(two_r): `d2 < thr` is exactly the reference's `dist < two_r`
 // (psim_threshold.h).
+// The part behind the test: dir = (dx, dy, dz), d2 = its squared length.
+__device__ __forceinline__ void attract_in_range(float &vx, float &vy, float &vz, float dx,
+                                                 float dy, float dz, float d2, float aforce,
+                                                 float two_r, float dt)
+{
+    const float dist = sqrtf(d2);                            // cpu.rs:77
+    const float t = 1.0f - dist / two_r;
+    const float ff = (t * t) * 2.0f;                         // cpu.rs:80 powi(2) * 2.0
+    const float inv = 1.0f / dist;                           // normalize = dir * (1/len)
+    const float fx = ((dx * inv) * aforce) * ff;             // cpu.rs:81
+    const float fy = ((dy * inv) * aforce) * ff;
+    const float fz = ((dz * inv) * aforce) * ff;
+    vx = vx + fx * dt;                                       // cpu.rs:82
+    vy = vy + fy * dt;
+    vz = vz + fz * dt;
+}
+
 __device__ __forceinline__ void attract(float &vx, float &vy, float &vz, float px, float py,
                                         float pz, float ax, float ay, float az, float aforce,
                                         float two_r, float thr, float dt)
 {
     const float dx = ax - px, dy = ay - py, dz = az - pz;    // cpu.rs:76
     const float d2 = (dx * dx + dy * dy) + dz * dz;
-    if (d2 < thr) {                                          // cpu.rs:79, see above
-        const float dist = sqrtf(d2);                        // cpu.rs:77
-        const float t = 1.0f - dist / two_r;
-        const float ff = (t * t) * 2.0f;                     // cpu.rs:80 powi(2) * 2.0
-        const float inv = 1.0f / dist;                       // normalize = dir * (1/len)
-        const float fx = ((dx * inv) * aforce) * ff;         // cpu.rs:81
-        const float fy = ((dy * inv) * aforce) * ff;
-        const float fz = ((dz * inv) * aforce) * ff;
-        vx = vx + fx * dt;                                   // cpu.rs:82
-        vy = vy + fy * dt;
-        vz = vz + fz * dt;
-    }
+    if (d2 < thr)                                            // cpu.rs:79, see above
+        attract_in_range(vx, vy, vz, dx, dy, dz, d2, aforce, two_r, dt);
 }
 
 template <int N>
 __device__ __forceinline__ void apply_gravity(float (&vy)[N], const psim_sim_params &p)
 {
     const float gdt = p.gravity * p.delta_time;
+    if constexpr (N == 4) {
+        // two particles per packed fp32 instruction; every element rounds as the scalar
+        // operation does
+        const f32x2 g2 = {gdt, gdt};
 #pragma unroll
-    for (int j = 0; j < N; ++j) vy[j] = vy[j] - gdt;         // cpu.rs:72
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 r = f32x2{vy[2 * h], vy[2 * h + 1]} - g2;
+            vy[2 * h] = r[0]; vy[2 * h + 1] = r[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) vy[j] = vy[j] - gdt;     // cpu.rs:72
+    }
 }
 
 template <int N>
@@ -145,14 +163,28 @@ __device__ __forceinline__ void integrate(float (&px)[N], float (&py)[N], float 
                                           const psim_sim_params &p)
 {
     const float dt = p.delta_time;
+    if constexpr (N == 4) {
+        const f32x2 dt2 = {dt, dt}, damp2 = {p.damping, p.damping};
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        px[j] = px[j] + vx[j] * dt;                          // cpu.rs:87
-        py[j] = py[j] + vy[j] * dt;
-        pz[j] = pz[j] + vz[j] * dt;
-        vx[j] = vx[j] * p.damping;                           // cpu.rs:90
-        vy[j] = vy[j] * p.damping;
-        vz[j] = vz[j] * p.damping;
+        for (int h = 0; h < 2; ++h) {
+            const int a = 2 * h, b = 2 * h + 1;
+            f32x2 x = {px[a], px[b]}, y = {py[a], py[b]}, z = {pz[a], pz[b]};
+            f32x2 u = {vx[a], vx[b]}, v = {vy[a], vy[b]}, w = {vz[a], vz[b]};
+            x = x + u * dt2; y = y + v * dt2; z = z + w * dt2;           // cpu.rs:87
+            u = u * damp2; v = v * damp2; w = w * damp2;                 // cpu.rs:90
+            px[a] = x[0]; px[b] = x[1]; py[a] = y[0]; py[b] = y[1]; pz[a] = z[0]; pz[b] = z[1];
+            vx[a] = u[0]; vx[b] = u[1]; vy[a] = v[0]; vy[b] = v[1]; vz[a] = w[0]; vz[b] = w[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            px[j] = px[j] + vx[j] * dt;                      // cpu.rs:87
+            py[j] = py[j] + vy[j] * dt;
+            pz[j] = pz[j] + vz[j] * dt;
+            vx[j] = vx[j] * p.damping;                       // cpu.rs:90
+            vy[j] = vy[j] * p.damping;
+            vz[j] = vz[j] * p.damping;
+        }
     }
 }
 
