@@ -165,7 +165,10 @@ int psim_update(psim_handle *h, const psim_sim_params *params);
  * `attractors_device` is DEVICE memory (e.g. the receive buffer of an RCCL
  * all-gather enqueued earlier on the same stream); it is read when the kernel
  * runs.  The mouse_* fields and is_mouse_dragging of `params` are ignored.
- * n_attractors <= PSIM_MAX_ATTRACTORS. */
+ * n_attractors <= PSIM_MAX_ATTRACTORS.  The kernel tests all (particle, attractor) pairs
+ * first and evaluates the force law only for the pairs in range, gathered wave by wave;
+ * the velocity terms are added per particle in index order, so the result is that of the
+ * plain loop, bit for bit. */
 int psim_update_multi(psim_handle *h, const psim_sim_params *params,
                       const psim_attractor *attractors_device, uint32_t n_attractors);
 
