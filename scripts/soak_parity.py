@@ -41,9 +41,9 @@ def stream(steps):
     return out
 
 
-def mixed_soak(n, steps, every):
+def mixed_soak(n, steps, every, n_list=3):
     """Every feature of the path in one run, on the reference's 64-byte records: colour modes
-    cycling, attractor lists of 3 (host list) every seventh step, fused batches on alternate
+    cycling, an attractor list (host list, 3 entries unless --attractors says otherwise) every seventh step, fused batches on alternate
     chunks, compute-shader colour semantics switched on for the second half."""
     lib = T.load_oracle()
     threads = int(lib.psim_oracle_max_threads())
@@ -51,9 +51,11 @@ def mixed_soak(n, steps, every):
     for i, p in enumerate(params):
         p.color_mode = (0, 1, 2, 0, 0, 1, 7)[(i // 5) % 7]
     rng = np.random.default_rng(3)
-    lst = np.zeros(3, dtype=psim.ATTRACTOR_DTYPE)
-    lst["position"] = rng.uniform(-40, 40, size=(3, 3)).astype(np.float32)
+    lst = np.zeros(n_list, dtype=psim.ATTRACTOR_DTYPE)
+    lst["position"] = rng.uniform(-40, 40, size=(n_list, 3)).astype(np.float32)
     lst["force"], lst["radius"], lst["active"] = 20.0, 15.0, 1
+    if n_list > 3:                                   # a spread of radii for longer lists
+        lst["radius"] = rng.choice(np.array([4.0, 10.0, 15.0], np.float32), n_list)
 
     sim = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
     ref = T.oracle_gen_uniform_aos(0, n)
@@ -84,7 +86,7 @@ def mixed_soak(n, steps, every):
                 else:
                     sim.update(params[i])
             lib.psim_oracle_update_aos(ref_ptr, n, ctypes.byref(params[i]),
-                                       lst_ptr if multi else None, 3 if multi else 0, threads)
+                                       lst_ptr if multi else None, n_list if multi else 0, threads)
             if params[i].color_mode in (1, 2):
                 dirty = True
             elif reset and dirty:                   # the shader's rule, applied to the oracle's state
@@ -110,12 +112,14 @@ def main():
     ap.add_argument("--particles", type=int, default=100_000_000)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--every", type=int, default=50)
+    ap.add_argument("--attractors", type=int, default=3,
+                    help="length of the attractor list of --mix (at most 8: a host list)")
     ap.add_argument("--mix", action="store_true",
                     help="colour modes, attractor lists, fused batches and colour semantics mixed")
     args = ap.parse_args()
     n = args.particles
     if args.mix:
-        return mixed_soak(n, args.steps, args.every)
+        return mixed_soak(n, args.steps, args.every, args.attractors)
     lib = T.load_oracle()
     threads = int(lib.psim_oracle_max_threads())
     params = stream(args.steps)
