@@ -202,6 +202,8 @@ __device__ __forceinline__ void integrate(float (&px)[N], float (&py)[N], float 
 // only, which do not change before all attractors are applied, so every term has the value
 // the loop would compute; the additions happen in the same order; the result is the same
 // bit for bit.  A chunk with more hits than the queue holds (large radii) takes the loop.
+// Sizes measured at 100 M particles, 64 attractors, r = 10 (ms per step; chunk / queue):
+// 16 / 256 2.34 | 32 / 512 2.39 | 16 / 512 2.54 | 8 / 256 2.63 | 32 / 256 6.99 (overflows).
 #define PSIM_PAIR_CHUNK 16u     /* attractors tested per round: the hit mask of a particle */
 #define PSIM_PAIR_QUEUE 256u    /* in-range (particle, attractor) pairs a wave queues per round */
 
