@@ -854,16 +854,21 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     // band: 7 (6.57-6.61 k against 6.28-6.48 k for 6).
     t.reserve_lds = cap ? ((stream || resident) ? 26624u : 23040u) : 0u;
     t.reserve_lds_colour = t.reserve_lds;
-    // A list of 2-5 attractors (worked off through the pair queue): 13 workgroups per CU
+    // A list of 2-4 attractors (worked off through the pair queue): 13 workgroups per CU
     // (ms per step at 100 M particles, 2 / 4 / 5 attractors: 13 resident 0.759 / 0.758 /
     // 0.760, 7 resident 1.01 / 1.06 / 1.07, 10 resident 0.843 / 0.864 / 0.877, uncapped
-    // 0.759 / 0.751 / 0.794); from 6 attractors on no cap (8 / 16 / 64 attractors: 0.768 /
-    // 0.899 / 2.40 uncapped, 0.830 / 1.14 / 3.25 with 13 resident).
+    // 0.759 / 0.751 / 0.794); 5-8 attractors 16 workgroups per CU, from 9 on no cap
+    // (8 / 16 / 64 attractors: 0.768 / 0.899 / 2.40 uncapped, 0.830 / 1.14 / 3.25 with 13
+    // resident).
     // States that do not stream run lists uncapped (6.25 M particles, 2 / 8 / 64 attractors,
     // us per step: 44 / 48 / 178 uncapped, 46 / 54 / 228 with 13 resident; 8 attractors
     // without the queue: 74).
+    // Finer, streaming, ms per step at 13 / 16 / 20 resident / uncapped: 5 attractors
+    // 0.767 / 0.757 / 0.762 / 0.765, 8: 0.810 / 0.754 / 0.763 / 0.781, 10: 0.883 / 0.789 /
+    // 0.775 / 0.767, 16: 1.06 / 0.911 / 0.880 / 0.851.
     if (n_attractors >= 2)
-        t.reserve_lds = t.reserve_lds_colour = (stream && n_attractors <= 5) ? 11776u : 0u;
+        t.reserve_lds = t.reserve_lds_colour =
+            !stream ? 0u : (n_attractors <= 4 ? 11776u : (n_attractors <= 8 ? 10240u : 0u));
     return t;
 }
 

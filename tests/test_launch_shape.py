@@ -34,11 +34,15 @@ def test_single_attractor_shape_by_size(count, access, reserve):
 def test_attractor_lists():
     for n in (6_250_000, 100_000_000):
         assert psim.launch_shape(n, 1)["reserve_lds"] == 26624
-    for a in (2, 3, 4, 5):                                     # streaming: 13 workgroups per CU
+    for a in (2, 3, 4):                                        # streaming: 13 workgroups per CU
         s = psim.launch_shape(100_000_000, a)
         assert s["reserve_lds"] == 11776 and s["resident_per_cu"] == 13
         assert psim.launch_shape(6_250_000, a)["reserve_lds"] == 0     # cache-resident: no cap
-    for a in (6, 8, 64):                                       # longer lists: no cap anywhere
+    for a in (5, 6, 8):                                        # streaming: 16 workgroups per CU
+        s = psim.launch_shape(100_000_000, a)
+        assert s["reserve_lds"] == 10240 and s["resident_per_cu"] == 16
+        assert psim.launch_shape(6_250_000, a)["reserve_lds"] == 0
+    for a in (9, 16, 64):                                      # longer lists: no cap anywhere
         assert psim.launch_shape(100_000_000, a)["reserve_lds"] == 0
         assert psim.launch_shape(6_250_000, a)["reserve_lds"] == 0
     assert psim.launch_shape(100_000, 8)["reserve_lds"] == 0
