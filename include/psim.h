@@ -367,6 +367,49 @@ typedef struct psim_launch_shape_info {
 } psim_launch_shape_info;
 int psim_launch_shape(uint32_t count, uint32_t n_attractors, psim_launch_shape_info *out);
 
+/* ---- several GPUs from one process ---------------------------------------- */
+
+/* A group is one particle set partitioned over several shards, each a psim_handle on a
+ * device of the caller's choice, driven by ONE host thread: what a single-process caller
+ * like the reference application (one `Box<dyn ParticleSimulation>`, src/app.rs:18) needs
+ * to use all GPUs of a node.  (Programs that run one process per GPU create their shard
+ * with psim_create_shard instead.)  Shard k owns the contiguous range
+ * [k * total / n, (k + 1) * total / n) and lives on device_ids[k]; a device may be named
+ * more than once.  Particles never read other particles (src/simulation/cpu.rs:65-113),
+ * so a step is one kernel per shard and no data moves between devices.  total_count may
+ * exceed 2^32 with PSIM_GEN_UNIFORM; the reference's two generators index with u32. */
+typedef struct psim_group psim_group;
+
+int psim_group_create(psim_group **out, uint64_t total_count, const int *device_ids,
+                      uint32_t n_shards, int generation_mode);
+void psim_group_destroy(psim_group *g);
+
+/* `update` on every shard: the kernels are enqueued device after device and run
+ * concurrently; returns without waiting (psim_group_sync waits for all). */
+int psim_group_update(psim_group *g, const psim_sim_params *params);
+int psim_group_update_batch(psim_group *g, const psim_sim_params *params_host, uint32_t n_steps);
+int psim_group_sync(psim_group *g);
+
+/* `reset` / `get_particle_count` of the whole set. */
+int psim_group_reset(psim_group *g, int generation_mode);
+uint64_t psim_group_particle_count(const psim_group *g);
+
+/* The shards, for everything per-shard (streams, raw pointers, colour semantics ...).
+ * The handles belong to the group: do not destroy or resize them. */
+uint32_t psim_group_shards(const psim_group *g);
+psim_handle *psim_group_shard(psim_group *g, uint32_t index);
+
+/* Particles [first, first + n) of the whole set as 64-byte records, to / from host memory,
+ * gathered from / scattered to the shards that hold them. */
+int psim_group_download_aos(psim_group *g, psim_particle *dst_host, uint64_t first, uint64_t n);
+int psim_group_upload_aos(psim_group *g, const psim_particle *src_host, uint64_t first, uint64_t n);
+
+/* The checksum of the whole set (sum of the shards' checksums) and a checkpoint of it in
+ * the one-file format above (every shard writes / reads its own records). */
+int psim_group_checksum(psim_group *g, uint64_t out[6]);
+int psim_group_checkpoint_write(psim_group *g, const char *path, uint64_t step);
+int psim_group_checkpoint_read(psim_group *g, const char *path, uint64_t *step_out);
+
 /* ---- errors --------------------------------------------------------------- */
 
 /* Text of the most recent failure on the calling thread ("" if none). */

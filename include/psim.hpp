@@ -211,6 +211,65 @@ private:
     psim_handle *h_ = nullptr;
 };
 
+// One particle set over several GPUs, driven from one process (psim_group_*): shard k lives
+// on device_ids[k].  The trait's methods apply to the whole set.
+class HipParticleGroup {
+public:
+    HipParticleGroup(uint64_t total_count, const std::vector<int> &device_ids,
+                     SphereGeneration generation_mode)
+    {
+        check(psim_group_create(&g_, total_count, device_ids.data(),
+                                static_cast<uint32_t>(device_ids.size()),
+                                static_cast<int>(generation_mode)));
+    }
+    ~HipParticleGroup() { psim_group_destroy(g_); }
+    HipParticleGroup(const HipParticleGroup &) = delete;
+    HipParticleGroup &operator=(const HipParticleGroup &) = delete;
+
+    void update(const SimParams &params) { check(psim_group_update(g_, &params)); }
+    void update_batch(const std::vector<SimParams> &params)
+    {
+        check(psim_group_update_batch(g_, params.data(), static_cast<uint32_t>(params.size())));
+    }
+    void sync() { check(psim_group_sync(g_)); }
+    void reset(SphereGeneration generation_mode)
+    {
+        check(psim_group_reset(g_, static_cast<int>(generation_mode)));
+    }
+    uint64_t get_particle_count() const { return psim_group_particle_count(g_); }
+    SimulationMethod get_method() const { return SimulationMethod::Hip; }
+    uint32_t shard_count() const { return psim_group_shards(g_); }
+    psim_handle *shard(uint32_t index) { return psim_group_shard(g_, index); }
+
+    std::vector<Particle> download()
+    {
+        std::vector<Particle> out(get_particle_count());
+        check(psim_group_download_aos(g_, out.data(), 0, out.size()));
+        return out;
+    }
+    void upload(const std::vector<Particle> &particles, uint64_t first = 0)
+    {
+        check(psim_group_upload_aos(g_, particles.data(), first, particles.size()));
+    }
+    void save_checkpoint(const std::string &path, uint64_t step = 0)
+    {
+        check(psim_group_checkpoint_write(g_, path.c_str(), step));
+    }
+    uint64_t load_checkpoint(const std::string &path)
+    {
+        uint64_t step = 0;
+        check(psim_group_checkpoint_read(g_, path.c_str(), &step));
+        return step;
+    }
+
+private:
+    static void check(int rc)
+    {
+        if (rc != PSIM_OK) throw Error(rc, psim_last_error());
+    }
+    psim_group *g_ = nullptr;
+};
+
 }  // namespace psim
 
 #endif  // PSIM_HPP

@@ -161,6 +161,20 @@ ABI = {
     "psim_checkpoint_write": (c_int, [_P, c_char_p, c_uint64]),
     "psim_checkpoint_read": (c_int, [_P, c_char_p, POINTER(c_uint64)]),
     "psim_checkpoint_info": (c_int, [c_char_p, POINTER(CheckpointHeader)]),
+    "psim_group_create": (c_int, [POINTER(_P), c_uint64, POINTER(c_int), c_uint32, c_int]),
+    "psim_group_destroy": (None, [_P]),
+    "psim_group_update": (c_int, [_P, POINTER(SimParams)]),
+    "psim_group_update_batch": (c_int, [_P, POINTER(SimParams), c_uint32]),
+    "psim_group_sync": (c_int, [_P]),
+    "psim_group_reset": (c_int, [_P, c_int]),
+    "psim_group_particle_count": (c_uint64, [_P]),
+    "psim_group_shards": (c_uint32, [_P]),
+    "psim_group_shard": (_P, [_P, c_uint32]),
+    "psim_group_download_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_group_upload_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_group_checksum": (c_int, [_P, POINTER(c_uint64)]),
+    "psim_group_checkpoint_write": (c_int, [_P, c_char_p, c_uint64]),
+    "psim_group_checkpoint_read": (c_int, [_P, c_char_p, POINTER(c_uint64)]),
     "psim_set_stream": (c_int, [_P, _P]),
     "psim_get_stream": (_P, [_P]),
     "psim_device": (c_int, [_P]),
@@ -418,6 +432,88 @@ class HipParticleSimulation:
     @property
     def handle(self):
         return self._h
+
+
+class HipParticleGroup:
+    """One particle set over several shards driven from one process (`psim_group_*`):
+    shard k lives on `device_ids[k]` and owns a contiguous index range."""
+
+    def __init__(self, total_count, device_ids, generation_mode=GEN_UNIFORM):
+        self._lib = load_library()
+        ids = (c_int * len(device_ids))(*device_ids)
+        g = c_void_p()
+        _check(self._lib.psim_group_create(byref(g), int(total_count), ids, len(device_ids),
+                                           generation_mode))
+        self._g = g
+
+    def close(self):
+        if self._g:
+            self._lib.psim_group_destroy(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, params):
+        _check(self._lib.psim_group_update(self._g, byref(params)))
+
+    def update_batch(self, params_list):
+        arr = (SimParams * len(params_list))(*params_list)
+        _check(self._lib.psim_group_update_batch(self._g, arr, len(params_list)))
+
+    def sync(self):
+        _check(self._lib.psim_group_sync(self._g))
+
+    def reset(self, generation_mode):
+        _check(self._lib.psim_group_reset(self._g, generation_mode))
+
+    def get_particle_count(self):
+        return int(self._lib.psim_group_particle_count(self._g))
+
+    def shard_count(self):
+        return int(self._lib.psim_group_shards(self._g))
+
+    def shard(self, index):
+        """Shard `index` as a HipParticleSimulation that does NOT own its handle."""
+        h = self._lib.psim_group_shard(self._g, index)
+        if not h:
+            raise IndexError(index)
+        sim = HipParticleSimulation(c_void_p(h))
+        sim.close = lambda: None                 # the group owns the handle
+        return sim
+
+    def download_aos(self, first=0, n=None):
+        n = self.get_particle_count() - first if n is None else n
+        out = np.empty(n, dtype=PARTICLE_DTYPE)
+        _check(self._lib.psim_group_download_aos(self._g, out.ctypes.data_as(c_void_p), first, n))
+        return out
+
+    def upload_aos(self, particles, first=0):
+        arr = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)
+        _check(self._lib.psim_group_upload_aos(self._g, arr.ctypes.data_as(c_void_p), first,
+                                               len(arr)))
+
+    def checksum(self):
+        out = (c_uint64 * 6)()
+        _check(self._lib.psim_group_checksum(self._g, out))
+        return [int(v) for v in out]
+
+    def save_checkpoint(self, path, step=0):
+        _check(self._lib.psim_group_checkpoint_write(self._g, os.fsencode(path), int(step)))
+
+    def load_checkpoint(self, path):
+        step = c_uint64(0)
+        _check(self._lib.psim_group_checkpoint_read(self._g, os.fsencode(path), byref(step)))
+        return int(step.value)
 
 
 def update_soa(px, py, pz, vx, vy, vz, color, count, params, stream=0):

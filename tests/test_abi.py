@@ -119,6 +119,17 @@ def test_null_arguments_are_rejected_without_a_device():
     assert lib.psim_set_color_semantics(None, 1) == 1
     assert lib.psim_color_semantics(None) == 0
     assert lib.psim_download_aos_async(None, None, 0, 0) == 1
+    g = ctypes.c_void_p()
+    ids = (ctypes.c_int * 2)(0, 0)
+    assert lib.psim_group_create(None, 10, ids, 2, 2) == 1
+    assert lib.psim_group_create(ctypes.byref(g), 10, None, 2, 2) == 1
+    assert lib.psim_group_create(ctypes.byref(g), 10, ids, 0, 2) == 1
+    assert lib.psim_group_create(ctypes.byref(g), 2**40, ids, 2, 2) == 1     # too many per shard
+    assert b"per shard" in lib.psim_last_error()
+    assert lib.psim_group_update(None, ctypes.byref(psim.SimParams())) == 1
+    assert lib.psim_group_particle_count(None) == 0 and lib.psim_group_shards(None) == 0
+    assert lib.psim_group_shard(None, 0) is None
+    lib.psim_group_destroy(None)                                # no-op
 
 
 @pytest.mark.skipif(T.gpu_available(), reason="a GPU is present")
