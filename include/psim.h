@@ -173,7 +173,10 @@ int psim_update_multi(psim_handle *h, const psim_sim_params *params,
                       const psim_attractor *attractors_device, uint32_t n_attractors);
 
 /* Same with the attractor list in HOST memory: copied by value into the launch,
- * no device buffer or synchronisation needed.  n_attractors <= 8. */
+ * no device buffer or synchronisation needed.  Lists of more than 8 (up to
+ * PSIM_MAX_ATTRACTORS) do not fit the kernel arguments: they are copied through one of four
+ * page-locked slots of the handle into its device scratch, in stream order; the call
+ * returns at once unless all four slots still wait for their copies. */
 int psim_update_multi_host(psim_handle *h, const psim_sim_params *params,
                            const psim_attractor *attractors_host, uint32_t n_attractors);
 

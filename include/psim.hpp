@@ -114,7 +114,7 @@ public:
         check(psim_update_batch(h_, params.data(), static_cast<uint32_t>(params.size())));
     }
 
-    // Multi-attractor extension, list in host memory (<= 8) or device memory (<= 64).
+    // Multi-attractor extension, list in host memory or device memory (<= 64 attractors).
     void update_multi(const SimParams &params, const std::vector<Attractor> &attractors)
     {
         check(psim_update_multi_host(h_, &params, attractors.data(),

@@ -102,7 +102,7 @@ GEN_HOLLOW, GEN_FILLED, GEN_UNIFORM = 0, 1, 2
 METHOD_CPU, METHOD_COMPUTE_SHADER, METHOD_HIP = 0, 1, 2
 COLOR_KEEP, COLOR_RESET = 0, 1      # cpu.rs:106 / compute.wgsl:75-77
 MAX_ATTRACTORS = 64
-MAX_HOST_ATTRACTORS = 8
+MAX_HOST_ATTRACTORS = 64     # lists of up to 8 travel in the kernel arguments, longer ones are staged
 
 # Every symbol include/psim.h declares: name -> (restype, argtypes).
 class LaunchShapeInfo(ctypes.Structure):
@@ -292,7 +292,7 @@ class HipParticleSimulation:
                                            c_void_p(attractors_device_ptr), n_attractors))
 
     def update_multi(self, params, attractors):
-        """Multi-attractor step with a host list (ATTRACTOR_DTYPE array, <= 8)."""
+        """Multi-attractor step with a host list (ATTRACTOR_DTYPE array, <= 64)."""
         arr = _as_attractors(attractors)
         _check(self._lib.psim_update_multi_host(self._h, byref(params),
                                                 arr.ctypes.data_as(c_void_p), len(arr)))

@@ -61,6 +61,8 @@ constexpr uint64_t kUniformSeed = 69;          // the reference's own seed, mod.
 constexpr uint32_t kStageParticles = 1u << 22; // AoS staging chunk: 4 Mi particles = 256 MiB
 constexpr uint32_t kBounceParticles = 1u << 19; // page-locked bounce slot: 512 Ki particles = 32 MiB
 constexpr uint32_t kCapacityQuantum = 1024;    // particles; keeps every array 4 KiB-granular
+constexpr uint32_t kListSlots = 4;             // host attractor lists in flight per handle
+constexpr uint64_t kScratchBytes = 256 + kListSlots * PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) + 3840;
 
 int env_int(const char *name, int dflt)
 {
@@ -115,6 +117,10 @@ struct psim_handle {
     void *slab = nullptr;       // one allocation, carved into `soa`
     psim::SoaPtrs soa = {};
     uint64_t *checksum_dev = nullptr;          // 8 x u64 inside the slab
+    psim_attractor *list_dev = nullptr;        // kListSlots attractor lists inside the slab
+    psim_attractor *list_host = nullptr;       // their page-locked staging
+    hipEvent_t list_copied[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t list_next = 0;
     psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
     uint32_t stage_particles = 0;              // its size
     psim_particle *bounce = nullptr;           // two page-locked slots for pageable downloads
@@ -143,7 +149,7 @@ int allocate(psim_handle *h, uint32_t capacity)
     const uint64_t cap = capacity;
     const uint64_t skew = (uint64_t)env_int("PSIM_SKEW_BYTES", 0) & ~255ull;
     const uint64_t f32_bytes = cap * 4 + skew;
-    const uint64_t total = 6 * f32_bytes + cap * 16 * 2 + cap * 8 + 4096;
+    const uint64_t total = 6 * f32_bytes + cap * 16 * 2 + cap * 8 + kScratchBytes;
     void *slab = nullptr;
     HIP_TRY(hipMalloc(&slab, total));
     char *b = static_cast<char *>(slab);
@@ -162,6 +168,7 @@ int allocate(psim_handle *h, uint32_t capacity)
     h->soa.padding = reinterpret_cast<float *>(b);
     b += cap * 8;
     h->checksum_dev = reinterpret_cast<uint64_t *>(b);
+    h->list_dev = reinterpret_cast<psim_attractor *>(b + 256);
     h->capacity = capacity;
     return PSIM_OK;
 }
@@ -402,6 +409,9 @@ PSIM_API void psim_destroy(psim_handle *h)
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->aos_stage) (void)hipFree(h->aos_stage);
     if (h->bounce) (void)hipHostFree(h->bounce);
+    if (h->list_host) (void)hipHostFree(h->list_host);
+    for (hipEvent_t e : h->list_copied)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->bounce_done)
         if (e) (void)hipEventDestroy(e);
     if (h->slab) (void)hipFree(h->slab);
@@ -464,10 +474,34 @@ PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *param
 {
     CHECK_HANDLE(h);
     if (!params) return fail(PSIM_ERR_INVALID, "null params");
-    if (n_attractors > PSIM_KERNARG_ATTRACTORS)
-        return fail(PSIM_ERR_INVALID, "%u attractors exceed the host-list maximum of %u",
-                    n_attractors, PSIM_KERNARG_ATTRACTORS);
+    if (n_attractors > PSIM_MAX_ATTRACTORS)
+        return fail(PSIM_ERR_INVALID, "%u attractors exceed the maximum of %u", n_attractors,
+                    PSIM_MAX_ATTRACTORS);
     if (n_attractors && !attractors_host) return fail(PSIM_ERR_INVALID, "null attractor list");
+    if (n_attractors > PSIM_KERNARG_ATTRACTORS) {
+        // Too long for the kernel arguments: through one of a few page-locked slots into the
+        // handle's own device scratch, in stream order.  A slot is reused only after its
+        // earlier copy has left the host.
+        static_assert(sizeof(h->list_copied) / sizeof(h->list_copied[0]) == kListSlots, "slots");
+        if (!h->list_host)
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->list_host),
+                                  kListSlots * PSIM_MAX_ATTRACTORS * sizeof(psim_attractor),
+                                  hipHostMallocDefault));
+        const uint32_t slot = h->list_next++ % kListSlots;
+        if (!h->list_copied[slot])
+            HIP_TRY(hipEventCreateWithFlags(&h->list_copied[slot], hipEventDisableTiming));
+        else
+            HIP_TRY(hipEventSynchronize(h->list_copied[slot]));
+        psim_attractor *host = h->list_host + slot * PSIM_MAX_ATTRACTORS;
+        psim_attractor *dev = h->list_dev + slot * PSIM_MAX_ATTRACTORS;
+        memcpy(host, attractors_host, n_attractors * sizeof(psim_attractor));
+        HIP_TRY(hipMemcpyAsync(dev, host, n_attractors * sizeof(psim_attractor),
+                               hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipEventRecord(h->list_copied[slot], h->stream));
+        HIP_TRY(psim::launch_update(h->soa, h->count, *params, 2, dev, nullptr, n_attractors,
+                                    tuning_for(h->count, n_attractors, h->overrides), h->stream));
+        return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
+    }
     const int force = n_attractors ? 3 : 0;
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, attractors_host,
                                 n_attractors, tuning_for(h->count, n_attractors, h->overrides),

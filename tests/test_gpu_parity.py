@@ -251,15 +251,38 @@ def test_long_lists_through_the_pair_queue(k, radius):
         for _ in range(3):
             sim.update_multi_device(params, buf, k)
         got = sim.download_aos()
-        if k <= 8:                                       # the same list from host memory
-            with Sim.new(n, psim.GEN_UNIFORM) as host_list:
-                host_list.upload_aos(start)
-                for _ in range(3):
-                    host_list.update_multi(params, attrs)
-                assert host_list.download_aos().tobytes() == got.tobytes()
+        # the same list from host memory (kernel arguments up to 8 attractors, staged beyond)
+        with Sim.new(n, psim.GEN_UNIFORM) as host_list:
+            host_list.upload_aos(start)
+            for _ in range(3):
+                host_list.update_multi(params, attrs)
+            assert host_list.download_aos().tobytes() == got.tobytes()
     want = T.oracle_update_aos(start, params, 3, attrs)
     T.assert_particles_equal(got, want, f"{k} attractors, radius {radius}")
     assert np.isnan(got["velocity"][12345]).any() == np.isnan(want["velocity"][12345]).any()
+
+
+def test_host_lists_reuse_their_staging_slots():
+    """Host lists longer than 8 attractors are staged through four page-locked slots: ten
+    different lists in a row, without a sync in between, must each reach their own step."""
+    rng = np.random.default_rng(99)
+    lists = []
+    for _ in range(10):
+        a = _attractors(rng, 20)
+        a["radius"] = np.float32(9.0)
+        lists.append(a)
+    params = T.bench_params(gravity=0.1)
+    n = 40_000
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        want = sim.download_aos()
+        for a in lists:
+            scratch = a.copy()
+            sim.update_multi(params, scratch)
+            scratch["position"] = 1000.0                 # the caller's array is free again
+        got = sim.download_aos()
+    for a in lists:
+        want = T.oracle_update_aos(want, params, 1, a)
+    T.assert_particles_equal(got, want, "ten staged host lists")
 
 
 def test_single_attractor_list_equals_update():

@@ -303,7 +303,7 @@ def test_error_codes():
         with pytest.raises(psim.PsimError):
             sim.resize_buffer(10, 42)
         with pytest.raises(psim.PsimError):
-            sim.update_multi(T.bench_params(), np.zeros(9, dtype=psim.ATTRACTOR_DTYPE))
+            sim.update_multi(T.bench_params(), np.zeros(65, dtype=psim.ATTRACTOR_DTYPE))
         with pytest.raises(psim.PsimError):
             sim.update_multi_device(T.bench_params(), 0, 3)
         with pytest.raises(psim.PsimError):
