@@ -1207,7 +1207,7 @@ PSIM_API int psim_group_create(psim_group **out, uint64_t total_count, const int
     if (!device_ids || n_shards == 0)
         return fail(PSIM_ERR_INVALID, "a group needs at least one device");
     if (n_shards > 1024) return fail(PSIM_ERR_INVALID, "%u shards: at most 1024", n_shards);
-    if ((total_count + n_shards - 1) / n_shards > kMaxParticles)
+    if (total_count / n_shards + (total_count % n_shards ? 1u : 0u) > kMaxParticles)
         return fail(PSIM_ERR_INVALID, "%llu particles over %u shards exceed %u per shard",
                     (unsigned long long)total_count, n_shards, kMaxParticles);
     psim_group *g = new (std::nothrow) psim_group();
@@ -1215,6 +1215,13 @@ PSIM_API int psim_group_create(psim_group **out, uint64_t total_count, const int
     g->total = total_count;
     // k * total / n without overflowing 64 bits: total = q * n + r
     const uint64_t q = total_count / n_shards, r = total_count % n_shards;
+    try {
+        g->shards.reserve(n_shards);
+        g->first.reserve(n_shards + 1u);
+    } catch (...) {
+        delete g;
+        return fail(PSIM_ERR_NOMEM, "host allocation failed");
+    }
     for (uint32_t k = 0; k <= n_shards; ++k) g->first.push_back(q * k + r * k / n_shards);
     for (uint32_t k = 0; k < n_shards; ++k) {
         psim_handle *h = nullptr;
