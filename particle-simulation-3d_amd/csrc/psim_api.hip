@@ -194,8 +194,22 @@ int ensure_stage(psim_handle *h)
 using psim_hostgen::gen_hollow;
 using psim_hostgen::gen_filled;
 
-// Fills particles [0, count) of the handle with `mode`.
+int generate_impl(psim_handle *h, int mode);
+
+// Fills particles [0, count) of the handle with `mode`.  The host generators use standard
+// containers and threads: nothing they throw may cross the C boundary.
 int generate(psim_handle *h, int mode)
+{
+    try {
+        return generate_impl(h, mode);
+    } catch (const std::bad_alloc &) {
+        return fail(PSIM_ERR_NOMEM, "host allocation failed while generating particles");
+    } catch (...) {
+        return fail(PSIM_ERR_HIP, "unexpected failure while generating particles");
+    }
+}
+
+int generate_impl(psim_handle *h, int mode)
 {
     h->colours_changed = false;                  // every generator writes colour = initial colour
     const uint64_t gfirst = h->global_first;
@@ -238,6 +252,8 @@ int generate(psim_handle *h, int mode)
         if (mode == PSIM_GEN_HOLLOW) gen_hollow(dst, gcount32, first, len);
         else gen_filled(dst, kUniformSeed, first, len);
     };
+    // built here, on this thread, where a failed allocation can still be reported
+    if (mode == PSIM_GEN_FILLED) (void)psim_hostgen::XoshiroPowers::get();
     const unsigned hw = std::thread::hardware_concurrency();
     uint64_t nchunk = 0;
     for (uint64_t done = 0; done < h->count; done += chunk, ++nchunk) {
