@@ -64,6 +64,8 @@ def cases(count, seed=20260128):
         n = int(rng.choice([1, 3, 4, 5, 63, 64, 65, 255, 257, 1000]))
         particles = random_particles(rng, n, 0.02 if wild else 0.0)
         params = random_params(rng, wild)
-        attractors = random_attractors(rng, int(rng.integers(1, 9)), wild) if i % 4 == 3 else None
+        # every fourth case a list: mostly 1-8 attractors, every sixteenth case 9-64
+        k = int(rng.integers(9, 65)) if i % 16 == 15 else int(rng.integers(1, 9))
+        attractors = random_attractors(rng, k, wild) if i % 4 == 3 else None
         steps = int(rng.choice([1, 2, 7]))
         yield i, particles, params, attractors, steps
