@@ -122,6 +122,16 @@ enum {
     PSIM_COLOR_RESET = 1   /* compute-shader semantics */
 };
 
+/* What `resize_buffer` does.  The reference's two backends disagree here as well: the
+ * compute backend regenerates all particles for the new count
+ * (src/simulation/compute.rs:146-193), the CPU backend keeps what it has, appends a fresh set
+ * of particles when it grows beyond everything generated so far and merely lowers the
+ * active count when it shrinks (src/simulation/cpu.rs:123-158). */
+enum {
+    PSIM_RESIZE_REGENERATE = 0,  /* compute-backend semantics (default) */
+    PSIM_RESIZE_APPEND     = 1   /* CPU-backend semantics */
+};
+
 /* ---- lifecycle ------------------------------------------------------------ */
 
 /* Replaces `ParticleSimulation::new` (src/simulation/mod.rs:22-29; call sites
@@ -220,6 +230,16 @@ int psim_sync(psim_handle *h);
  * new_count equals the current count; otherwise regenerates ALL particles for
  * new_count (state is lost); storage grows when needed and is kept on shrink. */
 int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode);
+
+/* Selects what psim_resize does from now on (PSIM_RESIZE_*).  Under PSIM_RESIZE_APPEND the
+ * handle behaves like the CPU backend's particle vector: growing past everything generated
+ * so far appends generate(new_count - generated, mode) -- a fresh set of that many
+ * particles -- behind the existing ones, whose state is kept (storage grows with a device
+ * copy); shrinking lowers the active count only; growing again within what was generated
+ * brings the same particles back as they were left.  psim_reset regenerates the active
+ * count and forgets the rest (cpu.rs:172-186).  Not available on shards. */
+int psim_set_resize_semantics(psim_handle *h, int semantics);
+int psim_resize_semantics(const psim_handle *h);
 
 /* Replaces `reset` (src/simulation/mod.rs:47; call site src/app.rs:336-343):
  * regenerates the current count of particles with `generation_mode`. */

@@ -159,6 +159,11 @@ public:
     void set_color_semantics(int semantics) { check(psim_set_color_semantics(h_, semantics)); }
     int get_color_semantics() const { return psim_color_semantics(h_); }
 
+    // What resize_buffer does: PSIM_RESIZE_REGENERATE (compute.rs:146-193, default) or
+    // PSIM_RESIZE_APPEND (cpu.rs:123-158).
+    void set_resize_semantics(int semantics) { check(psim_set_resize_semantics(h_, semantics)); }
+    int get_resize_semantics() const { return psim_resize_semantics(h_); }
+
     // `fn is_paused(&self) -> bool` / `fn set_paused(&mut self, paused: bool)`
     bool is_paused() const { return psim_is_paused(h_) != 0; }
     void set_paused(bool paused) { psim_set_paused(h_, paused ? 1 : 0); }

@@ -101,6 +101,7 @@ GEN_HOLLOW, GEN_FILLED, GEN_UNIFORM = 0, 1, 2
 # `enum SimulationMethod` (mod.rs:9-13) + this backend.
 METHOD_CPU, METHOD_COMPUTE_SHADER, METHOD_HIP = 0, 1, 2
 COLOR_KEEP, COLOR_RESET = 0, 1      # cpu.rs:106 / compute.wgsl:75-77
+RESIZE_REGENERATE, RESIZE_APPEND = 0, 1   # compute.rs:146-193 / cpu.rs:123-158
 MAX_ATTRACTORS = 64
 MAX_HOST_ATTRACTORS = 64     # lists of up to 8 travel in the kernel arguments, longer ones are staged
 
@@ -147,6 +148,8 @@ ABI = {
     "psim_set_paused": (None, [_P, c_int]),
     "psim_set_color_semantics": (c_int, [_P, c_int]),
     "psim_color_semantics": (c_int, [_P]),
+    "psim_set_resize_semantics": (c_int, [_P, c_int]),
+    "psim_resize_semantics": (c_int, [_P]),
     "psim_download_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_upload_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_download_aos_async": (c_int, [_P, _P, c_uint64, c_uint64]),
@@ -396,6 +399,13 @@ class HipParticleSimulation:
         out = (c_uint64 * 6)()
         _check(self._lib.psim_checksum(self._h, out))
         return [int(v) for v in out]
+
+    def set_resize_semantics(self, semantics):
+        """RESIZE_REGENERATE (compute backend, default) or RESIZE_APPEND (CPU backend)."""
+        _check(self._lib.psim_set_resize_semantics(self._h, semantics))
+
+    def get_resize_semantics(self):
+        return self._lib.psim_resize_semantics(self._h)
 
     # -- checkpoints
     def save_checkpoint(self, path, step=0):

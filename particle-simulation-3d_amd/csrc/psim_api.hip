@@ -113,6 +113,8 @@ struct psim_handle {
     int generation_mode = PSIM_GEN_HOLLOW;
     bool paused = false;
     int colour_semantics = PSIM_COLOR_KEEP;
+    int resize_semantics = PSIM_RESIZE_REGENERATE;
+    uint32_t watermark = 0;      // particles generated so far: the CPU backend's Vec length
     bool colours_changed = false;   // colour may differ from initial_colour
     void *slab = nullptr;       // one allocation, carved into `soa`
     psim::SoaPtrs soa = {};
@@ -194,14 +196,23 @@ int ensure_stage(psim_handle *h)
 using psim_hostgen::gen_hollow;
 using psim_hostgen::gen_filled;
 
-int generate_impl(psim_handle *h, int mode);
+// What to generate and where: particles [gen_first, gen_first + n) of a set of gen_total
+// particles, into the handle's particles [dst_first, dst_first + n).
+struct GenRange {
+    uint32_t dst_first;
+    uint32_t n;
+    uint64_t gen_first;
+    uint64_t gen_total;
+};
 
-// Fills particles [0, count) of the handle with `mode`.  The host generators use standard
-// containers and threads: nothing they throw may cross the C boundary.
-int generate(psim_handle *h, int mode)
+int generate_impl(psim_handle *h, int mode, const GenRange &r);
+
+// The host generators use standard containers and threads: nothing they throw may cross
+// the C boundary.
+int generate_range(psim_handle *h, int mode, const GenRange &r)
 {
     try {
-        return generate_impl(h, mode);
+        return generate_impl(h, mode, r);
     } catch (const std::bad_alloc &) {
         return fail(PSIM_ERR_NOMEM, "host allocation failed while generating particles");
     } catch (...) {
@@ -209,25 +220,39 @@ int generate(psim_handle *h, int mode)
     }
 }
 
-int generate_impl(psim_handle *h, int mode)
+// Fills particles [0, count) of the handle with `mode`: the handle's own index range of its
+// (possibly larger, sharded) set.
+int generate(psim_handle *h, int mode)
 {
     h->colours_changed = false;                  // every generator writes colour = initial colour
-    const uint64_t gfirst = h->global_first;
-    const uint32_t gcount32 =
-        (uint32_t)(h->global_count ? h->global_count : (uint64_t)h->count);
+    h->watermark = h->count;
+    return generate_range(h, mode, GenRange{0u, h->count, h->global_first,
+                                            h->global_count ? h->global_count : (uint64_t)h->count});
+}
+
+int generate_impl(psim_handle *h, int mode, const GenRange &r)
+{
+    const uint64_t gfirst = r.gen_first;
+    const uint32_t gcount32 = (uint32_t)r.gen_total;
+    const uint64_t count = r.n;
     if (mode == PSIM_GEN_UNIFORM) {
-        HIP_TRY(psim::launch_gen_uniform(h->soa, h->count, gfirst, kUniformSeed, h->stream));
+        psim::SoaPtrs at = h->soa;               // the arrays from particle dst_first on
+        at.px += r.dst_first; at.py += r.dst_first; at.pz += r.dst_first;
+        at.vx += r.dst_first; at.vy += r.dst_first; at.vz += r.dst_first;
+        at.color += 4ull * r.dst_first; at.initial_color += 4ull * r.dst_first;
+        at.padding += 2ull * r.dst_first;
+        HIP_TRY(psim::launch_gen_uniform(at, r.n, gfirst, kUniformSeed, h->stream));
         return PSIM_OK;
     }
     if (mode != PSIM_GEN_HOLLOW && mode != PSIM_GEN_FILLED)
         return fail(PSIM_ERR_INVALID, "unknown generation mode %d", mode);
-    if (h->count == 0) return PSIM_OK;
+    if (count == 0) return PSIM_OK;
     // Two page-locked chunks: while chunk k travels to the device and is transposed
     // there, the host threads already fill chunk k + 1.
     const uint64_t chunk = 1u << 20;
     static_assert(2 * (1u << 20) <= kStageParticles, "two chunks fit the device staging buffer");
-    const uint64_t slot_particles = h->count < chunk ? h->count : chunk;
-    const int slots = h->count > chunk ? 2 : 1;
+    const uint64_t slot_particles = count < chunk ? count : chunk;
+    const int slots = count > chunk ? 2 : 1;
     int rc = ensure_stage(h);
     if (rc != PSIM_OK) return rc;
     struct Staging {
@@ -256,8 +281,8 @@ int generate_impl(psim_handle *h, int mode)
     if (mode == PSIM_GEN_FILLED) (void)psim_hostgen::XoshiroPowers::get();
     const unsigned hw = std::thread::hardware_concurrency();
     uint64_t nchunk = 0;
-    for (uint64_t done = 0; done < h->count; done += chunk, ++nchunk) {
-        const uint64_t m = (h->count - done) < chunk ? (h->count - done) : chunk;
+    for (uint64_t done = 0; done < count; done += chunk, ++nchunk) {
+        const uint64_t m = (count - done) < chunk ? (count - done) : chunk;
         const int b = (int)(nchunk % (uint64_t)slots);
         psim_particle *host = st.host + (uint64_t)b * slot_particles;
         psim_particle *stage = h->aos_stage + (uint64_t)b * slot_particles;
@@ -278,7 +303,7 @@ int generate_impl(psim_handle *h, int mode)
         for (auto &t : pool) t.join();
         HIP_TRY(hipMemcpyAsync(stage, host, (size_t)m * sizeof(psim_particle),
                                hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)done, (uint32_t)m, stage, h->stream));
+        HIP_TRY(psim::launch_import_aos(h->soa, r.dst_first + (uint32_t)done, (uint32_t)m, stage, h->stream));
         HIP_TRY(hipEventRecord(st.done[b], h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));                    // before the staging goes away
@@ -580,6 +605,55 @@ PSIM_API int psim_sync(psim_handle *h)
 
 // ---- state management -------------------------------------------------------
 
+namespace {
+
+// `resize_buffer` of the reference's CPU backend (src/simulation/cpu.rs:123-158): its
+// particle vector only ever grows.  Growing past everything generated so far appends a
+// FRESH set of (new_count - generated) particles -- a whole new sphere of that size, not a
+// continuation of the old one (cpu.rs:138-140) -- and keeps every existing particle;
+// shrinking only lowers the active count, and growing again within what was generated brings
+// the same particles back as they were left.
+int resize_append(psim_handle *h, uint32_t new_count, int generation_mode)
+{
+    if (new_count > h->watermark) {
+        const uint32_t additional = new_count - h->watermark;
+        if (new_count > h->capacity) {               // cpu.rs:142-147: a larger buffer, state kept
+            const psim::SoaPtrs old = h->soa;
+            void *old_slab = h->slab;
+            int rc = allocate(h, round_capacity(new_count));
+            if (rc != PSIM_OK) return rc;            // old storage stays valid
+            const size_t w = h->watermark;
+            float *const from[6] = {old.px, old.py, old.pz, old.vx, old.vy, old.vz};
+            float *const to[6] = {h->soa.px, h->soa.py, h->soa.pz, h->soa.vx, h->soa.vy, h->soa.vz};
+            hipError_t e = hipSuccess;
+            for (int k = 0; k < 6 && e == hipSuccess; ++k)
+                e = hipMemcpyAsync(to[k], from[k], w * 4, hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(h->soa.color, old.color, w * 16, hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(h->soa.initial_color, old.initial_color, w * 16,
+                                   hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(h->soa.padding, old.padding, w * 8, hipMemcpyDeviceToDevice,
+                                   h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            (void)hipFree(old_slab);
+            if (e != hipSuccess)
+                return fail(PSIM_ERR_HIP, "copying the particles into the larger buffer failed: %s",
+                            hipGetErrorString(e));
+        }
+        const int rc = generate_range(h, generation_mode,
+                                      GenRange{h->watermark, additional, 0, additional});
+        if (rc != PSIM_OK) return rc;
+        h->watermark = new_count;
+    }
+    h->count = new_count;                            // cpu.rs:150
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PSIM_OK;
+}
+
+}  // namespace
+
 PSIM_API int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode)
 {
     CHECK_HANDLE(h);
@@ -593,6 +667,7 @@ PSIM_API int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode
     if (h->global_count)
         return fail(PSIM_ERR_INVALID, "a shard cannot be resized; recreate the shards");
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->resize_semantics == PSIM_RESIZE_APPEND) return resize_append(h, new_count, generation_mode);
     if (new_count > h->capacity) {                   // compute.rs:162-186: new buffer
         void *old = h->slab;
         int rc = allocate(h, round_capacity(new_count));
@@ -604,6 +679,22 @@ PSIM_API int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode
     if (rc != PSIM_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return PSIM_OK;
+}
+
+PSIM_API int psim_set_resize_semantics(psim_handle *h, int semantics)
+{
+    CHECK_HANDLE(h);
+    if (semantics != PSIM_RESIZE_REGENERATE && semantics != PSIM_RESIZE_APPEND)
+        return fail(PSIM_ERR_INVALID, "unknown resize semantics %d", semantics);
+    if (semantics == PSIM_RESIZE_APPEND && h->global_count)
+        return fail(PSIM_ERR_INVALID, "a shard cannot be resized; recreate the shards");
+    h->resize_semantics = semantics;
+    return PSIM_OK;
+}
+
+PSIM_API int psim_resize_semantics(const psim_handle *h)
+{
+    return h ? h->resize_semantics : PSIM_RESIZE_REGENERATE;
 }
 
 PSIM_API int psim_reset(psim_handle *h, int generation_mode)

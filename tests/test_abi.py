@@ -118,6 +118,8 @@ def test_null_arguments_are_rejected_without_a_device():
     lib.psim_host_free(None)                                    # no-op
     assert lib.psim_set_color_semantics(None, 1) == 1
     assert lib.psim_color_semantics(None) == 0
+    assert lib.psim_set_resize_semantics(None, 1) == 1
+    assert lib.psim_resize_semantics(None) == 0
     assert lib.psim_download_aos_async(None, None, 0, 0) == 1
     g = ctypes.c_void_p()
     ids = (ctypes.c_int * 2)(0, 0)

@@ -320,3 +320,63 @@ def test_timer_reports_device_time():
             sim.update(T.bench_params())
         ms = sim.timer_stop()
         assert 0.0 < ms < 1000.0
+
+
+# ---- the CPU backend's resize semantics -------------------------------------------------------
+
+def _generated(mode, n):
+    return T.oracle_gen_hollow_aos(n) if mode == psim.GEN_HOLLOW else T.oracle_gen_filled_aos(0, n)
+
+
+@pytest.mark.parametrize("mode", [psim.GEN_HOLLOW, psim.GEN_FILLED])
+def test_cpu_backend_resize_semantics(mode):
+    """PSIM_RESIZE_APPEND follows src/simulation/cpu.rs:123-186: growing appends a fresh set
+    of the additional particles and keeps the stepped ones (also across a reallocation),
+    shrinking only hides the tail, growing back reveals it unchanged, reset forgets it."""
+    params = T.bench_params(mouse_radius=40.0, gravity=1.0)
+    with Sim.new(1000, mode) as sim:
+        sim.set_resize_semantics(psim.RESIZE_APPEND)
+        assert sim.get_resize_semantics() == psim.RESIZE_APPEND
+        for _ in range(3):
+            sim.update(params)
+        model = T.oracle_update_aos(_generated(mode, 1000), params, 3)
+        # grow within the allocation's slack (capacity is a multiple of 1024)
+        sim.resize_buffer(1020, mode)
+        model = np.concatenate([model, _generated(mode, 20)])
+        T.assert_particles_equal(sim.download_aos(), model, "grown by 20")
+        # grow past the allocation: a larger buffer, every particle kept
+        sim.update(params)
+        model = T.oracle_update_aos(model, params)
+        other = psim.GEN_FILLED if mode == psim.GEN_HOLLOW else psim.GEN_HOLLOW
+        sim.resize_buffer(5000, other)                   # the mode of the call generates
+        model = np.concatenate([model, _generated(other, 3980)])
+        T.assert_particles_equal(sim.download_aos(), model, "grown past the capacity")
+        # shrink: the tail is hidden and frozen while the head steps on
+        sim.resize_buffer(700, mode)
+        assert sim.get_particle_count() == 700
+        sim.update(params)
+        model[:700] = T.oracle_update_aos(model[:700], params)
+        T.assert_particles_equal(sim.download_aos(), model[:700], "shrunk")
+        # grow back within what was generated: nothing new, the frozen tail returns
+        sim.resize_buffer(4000, mode)
+        T.assert_particles_equal(sim.download_aos(), model[:4000], "grown back")
+        # same count: no-op
+        sim.resize_buffer(4000, other)
+        T.assert_particles_equal(sim.download_aos(), model[:4000], "no-op")
+        # reset regenerates the active count and forgets the rest (cpu.rs:172-186)
+        sim.reset(mode)
+        T.assert_particles_equal(sim.download_aos(), _generated(mode, 4000), "reset")
+        sim.resize_buffer(4500, mode)
+        T.assert_particles_equal(sim.download_aos(),
+                                 np.concatenate([_generated(mode, 4000), _generated(mode, 500)]),
+                                 "grown after reset: 4000 is the new high-water mark")
+        # back to the compute backend's rule: everything regenerated
+        sim.set_resize_semantics(psim.RESIZE_REGENERATE)
+        sim.resize_buffer(300, mode)
+        T.assert_particles_equal(sim.download_aos(), _generated(mode, 300), "regenerated")
+
+
+def test_append_is_refused_on_shards():
+    with Sim.new_shard(100, 50, 1000, psim.GEN_UNIFORM) as shard:
+        with pytest.raises(psim.PsimError):
+            shard.set_resize_semantics(psim.RESIZE_APPEND)
