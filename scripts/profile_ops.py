@@ -52,8 +52,6 @@ def main():
          lambda: sim.update(P(mouse_radius=50.0, color_mode=1))),
         ("update_kernel<2, 1, 2>", "update, r=50, colour mode 2", 64 * n,
          lambda: sim.update(P(mouse_radius=50.0, color_mode=2))),
-        ("update_kernel<0, 3, 2>", "update, list of 1 attractor in kernel arguments", 48 * n,
-         lambda: sim.update_multi(P(), a8[:1])),
         ("update_kernel<0, 4, 2>", "update, 8 attractors r=10 through the pair queue", 48 * n,
          lambda: sim.update_multi_device(P(), attr_buf, 8)),
         ("update_batch_kernel<2>", "16 fused steps", 48 * n,
