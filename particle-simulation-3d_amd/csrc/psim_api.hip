@@ -99,6 +99,21 @@ psim::LaunchTuning tuning_for(uint32_t n, uint32_t n_attractors, const TuningOve
     return t;
 }
 
+// Fused passes: 2-4 steps are still HBM-bound and run 13 workgroups per CU on states of
+// 96 MB and more; from 5 steps on the pass is VALU-bound and runs uncapped (100 M particles,
+// ms per pass at 13 resident / uncapped: 2 steps 0.778 / 0.841, 4: 0.766 / 0.842, 8: 1.196 /
+// 0.962, 16: 2.26 / 1.88).
+psim::LaunchTuning batch_tuning_for(uint32_t n, uint32_t steps, const TuningOverrides &o)
+{
+    if (steps <= 1) return tuning_for(n, 1, o);
+    TuningOverrides access_only = o;
+    access_only.reserve_lds = -1;
+    psim::LaunchTuning t = tuning_for(n, 1, access_only);
+    t.reserve_lds = t.reserve_lds_colour = (24ull * n >= 96000000ull && steps <= 4) ? 11776u : 0u;
+    if (o.reserve_lds >= 0) t.reserve_lds = t.reserve_lds_colour = (uint32_t)o.reserve_lds;
+    return t;
+}
+
 }  // namespace
 
 struct psim_handle {
@@ -482,10 +497,8 @@ PSIM_API int psim_update_batch(psim_handle *h, const psim_sim_params *params_hos
     for (uint32_t done = 0; done < n_steps; done += PSIM_BATCH_STEPS) {
         const uint32_t m = (n_steps - done) < PSIM_BATCH_STEPS ? (n_steps - done)
                                                                 : PSIM_BATCH_STEPS;
-        // a fused pass of >= 4 steps is VALU-bound: treat it like a long attractor list
-        // (no cap on resident waves)
         HIP_TRY(psim::launch_update_batch(h->soa, h->count, params_host + done, m,
-                                          tuning_for(h->count, m, h->overrides), h->stream));
+                                          batch_tuning_for(h->count, m, h->overrides), h->stream));
     }
     bool wrote = false;
     for (uint32_t k = 0; k < n_steps; ++k) wrote = wrote || is_colour_mode(params_host[k].color_mode);
