@@ -411,6 +411,11 @@ void psim_group_destroy(psim_group *g);
  * concurrently; returns without waiting (psim_group_sync waits for all). */
 int psim_group_update(psim_group *g, const psim_sim_params *params);
 int psim_group_update_batch(psim_group *g, const psim_sim_params *params_host, uint32_t n_steps);
+/* The multi-attractor step on every shard with one host list: in a single process every
+ * attractor is known to the host, so the several-GPU multi-attractor configuration needs
+ * no exchange between devices at all. */
+int psim_group_update_multi_host(psim_group *g, const psim_sim_params *params,
+                                 const psim_attractor *attractors_host, uint32_t n_attractors);
 int psim_group_sync(psim_group *g);
 
 /* `reset` / `get_particle_count` of the whole set. */

@@ -236,6 +236,11 @@ public:
     {
         check(psim_group_update_batch(g_, params.data(), static_cast<uint32_t>(params.size())));
     }
+    void update_multi(const SimParams &params, const std::vector<Attractor> &attractors)
+    {
+        check(psim_group_update_multi_host(g_, &params, attractors.data(),
+                                           static_cast<uint32_t>(attractors.size())));
+    }
     void sync() { check(psim_group_sync(g_)); }
     void reset(SphereGeneration generation_mode)
     {

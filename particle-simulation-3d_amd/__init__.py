@@ -168,6 +168,7 @@ ABI = {
     "psim_group_destroy": (None, [_P]),
     "psim_group_update": (c_int, [_P, POINTER(SimParams)]),
     "psim_group_update_batch": (c_int, [_P, POINTER(SimParams), c_uint32]),
+    "psim_group_update_multi_host": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
     "psim_group_sync": (c_int, [_P]),
     "psim_group_reset": (c_int, [_P, c_int]),
     "psim_group_particle_count": (c_uint64, [_P]),
@@ -479,6 +480,11 @@ class HipParticleGroup:
     def update_batch(self, params_list):
         arr = (SimParams * len(params_list))(*params_list)
         _check(self._lib.psim_group_update_batch(self._g, arr, len(params_list)))
+
+    def update_multi(self, params, attractors):
+        arr = _as_attractors(attractors)
+        _check(self._lib.psim_group_update_multi_host(self._g, byref(params),
+                                                      arr.ctypes.data_as(c_void_p), len(arr)))
 
     def sync(self):
         _check(self._lib.psim_group_sync(self._g))

@@ -1405,6 +1405,18 @@ PSIM_API int psim_group_update_batch(psim_group *g, const psim_sim_params *param
     return PSIM_OK;
 }
 
+PSIM_API int psim_group_update_multi_host(psim_group *g, const psim_sim_params *params,
+                                          const psim_attractor *attractors_host,
+                                          uint32_t n_attractors)
+{
+    if (!g) return fail(PSIM_ERR_INVALID, "null group");
+    for (psim_handle *h : g->shards) {
+        const int rc = psim_update_multi_host(h, params, attractors_host, n_attractors);
+        if (rc != PSIM_OK) return rc;
+    }
+    return PSIM_OK;
+}
+
 PSIM_API int psim_group_sync(psim_group *g)
 {
     if (!g) return fail(PSIM_ERR_INVALID, "null group");

@@ -86,3 +86,20 @@ def test_bad_device_is_reported():
     with pytest.raises(psim.PsimError) as e:
         Group(1000, [0, 99])
     assert e.value.code == 1 and "99" in str(e.value)
+
+
+@pytest.mark.parametrize("k", [1, 8, 20])
+def test_group_multi_attractor_step(k):
+    """One host list for every shard: the several-GPU multi-attractor configuration of a
+    single process needs no exchange between devices."""
+    rng = np.random.default_rng(k)
+    attrs = np.zeros(k, dtype=psim.ATTRACTOR_DTYPE)
+    attrs["position"] = rng.uniform(-40, 40, size=(k, 3)).astype(np.float32)
+    attrs["force"], attrs["radius"], attrs["active"] = 20.0, 12.0, 1
+    total = 50_003
+    with Group(total, [0, 0, 0], psim.GEN_UNIFORM) as g:
+        start = g.download_aos()
+        for _ in range(3):
+            g.update_multi(params(), attrs)
+        got = g.download_aos()
+    T.assert_particles_equal(got, T.oracle_update_aos(start, params(), 3, attrs), f"{k} attractors")
