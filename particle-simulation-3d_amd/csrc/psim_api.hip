@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 
+#include "psim_checkpoint_file.h"
 #include "psim_hostgen.h"
 #include "psim_kernels.h"
 
@@ -47,6 +48,20 @@ int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+
+}  // namespace
+
+// The error sink of psim_checkpoint_file.h.
+int psim_ckpt_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
 
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
@@ -1121,65 +1136,12 @@ PSIM_API int psim_checksum(psim_handle *h, uint64_t out[6])
 
 namespace {
 
-const char kCheckpointMagic[8] = {'P', 'S', 'I', 'M', 'C', 'K', 'P', '1'};
-
-struct File {
-    int fd = -1;
-    ~File()
-    {
-        if (fd >= 0) (void)close(fd);
-    }
-};
-
-int write_all(int fd, const void *buf, size_t bytes, uint64_t offset, const char *path)
-{
-    const char *p = static_cast<const char *>(buf);
-    while (bytes) {
-        const ssize_t w = pwrite(fd, p, bytes, (off_t)offset);
-        if (w < 0 && errno == EINTR) continue;
-        if (w <= 0) return fail(PSIM_ERR_IO, "write to %s failed: %s", path, strerror(errno));
-        p += w, bytes -= (size_t)w, offset += (uint64_t)w;
-    }
-    return PSIM_OK;
-}
-
-int read_all(int fd, void *buf, size_t bytes, uint64_t offset, const char *path)
-{
-    char *p = static_cast<char *>(buf);
-    while (bytes) {
-        const ssize_t r = pread(fd, p, bytes, (off_t)offset);
-        if (r < 0 && errno == EINTR) continue;
-        if (r < 0) return fail(PSIM_ERR_IO, "read from %s failed: %s", path, strerror(errno));
-        if (r == 0) return fail(PSIM_ERR_IO, "%s is shorter than its header says", path);
-        p += r, bytes -= (size_t)r, offset += (uint64_t)r;
-    }
-    return PSIM_OK;
-}
-
-int read_header(int fd, const char *path, psim_checkpoint_header *out)
-{
-    struct stat st;
-    if (fstat(fd, &st) != 0) return fail(PSIM_ERR_IO, "stat of %s failed: %s", path, strerror(errno));
-    if ((uint64_t)st.st_size < sizeof(*out))
-        return fail(PSIM_ERR_IO, "%s is too short to be a checkpoint", path);
-    int rc = read_all(fd, out, sizeof(*out), 0, path);
-    if (rc != PSIM_OK) return rc;
-    if (memcmp(out->magic, kCheckpointMagic, sizeof(kCheckpointMagic)) != 0)
-        return fail(PSIM_ERR_IO, "%s is not a checkpoint (or its write was interrupted)", path);
-    if (out->version != 1u || out->record_bytes != sizeof(psim_particle))
-        return fail(PSIM_ERR_IO, "%s: unsupported checkpoint version %u / record size %u", path,
-                    out->version, out->record_bytes);
-    const uint64_t room = ((uint64_t)st.st_size - sizeof(*out)) / sizeof(psim_particle);
-    if (out->particle_count > room)
-        return fail(PSIM_ERR_IO, "%s holds %llu records, its header says %llu", path,
-                    (unsigned long long)room, (unsigned long long)out->particle_count);
-    return PSIM_OK;
-}
-
-uint64_t record_offset(uint64_t particle)
-{
-    return sizeof(psim_checkpoint_header) + particle * sizeof(psim_particle);
-}
+using psim_ckpt::File;
+using psim_ckpt::kCheckpointMagic;
+using psim_ckpt::read_all;
+using psim_ckpt::read_header;
+using psim_ckpt::record_offset;
+using psim_ckpt::write_all;
 
 }  // namespace
 
@@ -1210,13 +1172,8 @@ PSIM_API int psim_checkpoint_write(psim_handle *h, const char *path, uint64_t st
     if (first + h->count == total && ftruncate(f.fd, (off_t)record_offset(total)) != 0)
         return fail(PSIM_ERR_IO, "cannot size %s: %s", path, strerror(errno));
     if (first == 0) {
-        memcpy(hdr.magic, kCheckpointMagic, sizeof(kCheckpointMagic));
-        hdr.version = 1;
-        hdr.record_bytes = sizeof(psim_particle);
-        hdr.particle_count = total;
-        hdr.step = step;
-        hdr.generation_mode = (uint32_t)h->generation_mode;
-        hdr.color_semantics = (uint32_t)h->colour_semantics;
+        hdr = psim_ckpt::make_header(total, step, (uint32_t)h->generation_mode,
+                                     (uint32_t)h->colour_semantics);
         rc = write_all(f.fd, &hdr, sizeof(hdr), 0, path);
         if (rc != PSIM_OK) return rc;
     }

@@ -2,6 +2,8 @@
 psim_checkpoint_info and the record view, on files written here with numpy."""
 import ctypes
 import importlib
+import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -93,3 +95,17 @@ def test_null_arguments():
     assert lib.psim_checkpoint_info(b"/tmp/x", None) == 1
     assert lib.psim_checkpoint_write(None, b"/tmp/x", 0) == 1
     assert lib.psim_checkpoint_read(None, b"/tmp/x", None) == 1
+
+
+def test_file_helpers_under_the_host_sanitizers(tmp_path):
+    """csrc/psim_checkpoint_file.h alone (tests/cpp/checkpoint_file_check.cpp), built with a
+    plain host compiler under AddressSanitizer + UBSan: out-of-order piecewise writes, read
+    back, every kind of broken file."""
+    cpp_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.check_call(["make", "-C", cpp_dir, "checkpoint_file_check"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(cpp_dir, "checkpoint_file_check"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "checkpoint file ok" in r.stdout
+    # the file it wrote is one the library accepts
+    assert psim.checkpoint_info(tmp_path / "pieces.ckp")["step"] == 77
