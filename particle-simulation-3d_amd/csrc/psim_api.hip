@@ -52,7 +52,7 @@ int fail(int code, const char *fmt, ...)
 }  // namespace
 
 // The error sink of psim_checkpoint_file.h.
-int psim_ckpt_fail(int code, const char *fmt, ...)
+int psim_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -1253,228 +1253,6 @@ PSIM_API int psim_timer_stop(psim_handle *h, float *elapsed_ms)
     HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev_stop));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_start, h->ev_stop));
-    return PSIM_OK;
-}
-
-// ---- several GPUs from one process ------------------------------------------------
-
-struct psim_group {
-    uint64_t total = 0;
-    std::vector<psim_handle *> shards;
-    std::vector<uint64_t> first;     // first[k] = first particle of shard k; first[n] = total
-};
-
-namespace {
-
-// For every shard that overlaps [first, first + n): call fn(shard, first_in_shard, count,
-// offset_in_request).
-template <typename Fn>
-int for_overlapping_shards(psim_group *g, uint64_t first, uint64_t n, Fn fn)
-{
-    for (size_t k = 0; k < g->shards.size(); ++k) {
-        const uint64_t lo = first > g->first[k] ? first : g->first[k];
-        const uint64_t hi = first + n < g->first[k + 1] ? first + n : g->first[k + 1];
-        if (lo >= hi) continue;
-        const int rc = fn(g->shards[k], lo - g->first[k], hi - lo, lo - first);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
-}
-
-int check_group_range(const psim_group *g, uint64_t first, uint64_t n)
-{
-    if (first > g->total || n > g->total - first)
-        return fail(PSIM_ERR_INVALID, "range [%llu, +%llu) exceeds particle count %llu",
-                    (unsigned long long)first, (unsigned long long)n,
-                    (unsigned long long)g->total);
-    return PSIM_OK;
-}
-
-}  // namespace
-
-PSIM_API int psim_group_create(psim_group **out, uint64_t total_count, const int *device_ids,
-                               uint32_t n_shards, int generation_mode)
-{
-    if (!out) return fail(PSIM_ERR_INVALID, "null out pointer");
-    *out = nullptr;
-    if (!device_ids || n_shards == 0)
-        return fail(PSIM_ERR_INVALID, "a group needs at least one device");
-    if (n_shards > 1024) return fail(PSIM_ERR_INVALID, "%u shards: at most 1024", n_shards);
-    if (total_count / n_shards + (total_count % n_shards ? 1u : 0u) > kMaxParticles)
-        return fail(PSIM_ERR_INVALID, "%llu particles over %u shards exceed %u per shard",
-                    (unsigned long long)total_count, n_shards, kMaxParticles);
-    psim_group *g = new (std::nothrow) psim_group();
-    if (!g) return fail(PSIM_ERR_NOMEM, "host allocation failed");
-    g->total = total_count;
-    // k * total / n without overflowing 64 bits: total = q * n + r
-    const uint64_t q = total_count / n_shards, r = total_count % n_shards;
-    try {
-        g->shards.reserve(n_shards);
-        g->first.reserve(n_shards + 1u);
-    } catch (...) {
-        delete g;
-        return fail(PSIM_ERR_NOMEM, "host allocation failed");
-    }
-    for (uint32_t k = 0; k <= n_shards; ++k) g->first.push_back(q * k + r * k / n_shards);
-    for (uint32_t k = 0; k < n_shards; ++k) {
-        psim_handle *h = nullptr;
-        const uint32_t count = (uint32_t)(g->first[k + 1] - g->first[k]);
-        // a set of one shard still is a shard of itself: global_count must be non-zero
-        const int rc = total_count == 0
-                           ? create_impl(&h, 0, 0, 0, generation_mode, device_ids[k])
-                           : create_impl(&h, count, g->first[k], total_count, generation_mode,
-                                         device_ids[k]);
-        if (rc != PSIM_OK) {
-            psim_group_destroy(g);
-            return rc;
-        }
-        g->shards.push_back(h);
-    }
-    *out = g;
-    return PSIM_OK;
-}
-
-PSIM_API void psim_group_destroy(psim_group *g)
-{
-    if (!g) return;
-    for (psim_handle *h : g->shards) psim_destroy(h);
-    delete g;
-}
-
-PSIM_API int psim_group_update(psim_group *g, const psim_sim_params *params)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_update(h, params);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
-}
-
-PSIM_API int psim_group_update_batch(psim_group *g, const psim_sim_params *params_host,
-                                     uint32_t n_steps)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_update_batch(h, params_host, n_steps);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
-}
-
-PSIM_API int psim_group_update_multi_host(psim_group *g, const psim_sim_params *params,
-                                          const psim_attractor *attractors_host,
-                                          uint32_t n_attractors)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_update_multi_host(h, params, attractors_host, n_attractors);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
-}
-
-PSIM_API int psim_group_sync(psim_group *g)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_sync(h);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
-}
-
-PSIM_API int psim_group_reset(psim_group *g, int generation_mode)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_reset(h, generation_mode);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
-}
-
-PSIM_API uint64_t psim_group_particle_count(const psim_group *g) { return g ? g->total : 0; }
-
-PSIM_API uint32_t psim_group_shards(const psim_group *g)
-{
-    return g ? (uint32_t)g->shards.size() : 0;
-}
-
-PSIM_API psim_handle *psim_group_shard(psim_group *g, uint32_t index)
-{
-    return g && index < g->shards.size() ? g->shards[index] : nullptr;
-}
-
-PSIM_API int psim_group_download_aos(psim_group *g, psim_particle *dst_host, uint64_t first,
-                                     uint64_t n)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    int rc = check_group_range(g, first, n);
-    if (rc != PSIM_OK) return rc;
-    if (n && !dst_host) return fail(PSIM_ERR_INVALID, "null destination");
-    return for_overlapping_shards(g, first, n,
-                                  [dst_host](psim_handle *h, uint64_t f, uint64_t m, uint64_t off) {
-                                      return psim_download_aos(h, dst_host + off, f, m);
-                                  });
-}
-
-PSIM_API int psim_group_upload_aos(psim_group *g, const psim_particle *src_host, uint64_t first,
-                                   uint64_t n)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    int rc = check_group_range(g, first, n);
-    if (rc != PSIM_OK) return rc;
-    if (n && !src_host) return fail(PSIM_ERR_INVALID, "null source");
-    return for_overlapping_shards(g, first, n,
-                                  [src_host](psim_handle *h, uint64_t f, uint64_t m, uint64_t off) {
-                                      return psim_upload_aos(h, src_host + off, f, m);
-                                  });
-}
-
-PSIM_API int psim_group_checksum(psim_group *g, uint64_t out[6])
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    if (!out) return fail(PSIM_ERR_INVALID, "null output");
-    for (int c = 0; c < 6; ++c) out[c] = 0;
-    for (psim_handle *h : g->shards) {
-        uint64_t part[6];
-        const int rc = psim_checksum(h, part);
-        if (rc != PSIM_OK) return rc;
-        for (int c = 0; c < 6; ++c) out[c] += part[c];
-    }
-    return PSIM_OK;
-}
-
-PSIM_API int psim_group_checkpoint_write(psim_group *g, const char *path, uint64_t step)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    if (!path) return fail(PSIM_ERR_INVALID, "null path");
-    {                                            // no valid header while the records change
-        File f;
-        f.fd = open(path, O_WRONLY | O_CREAT | O_CLOEXEC, 0644);
-        if (f.fd < 0)
-            return fail(PSIM_ERR_IO, "cannot open %s for writing: %s", path, strerror(errno));
-        psim_checkpoint_header zero;
-        memset(&zero, 0, sizeof(zero));
-        const int rc = write_all(f.fd, &zero, sizeof(zero), 0, path);
-        if (rc != PSIM_OK) return rc;
-    }
-    // the shard that owns particle 0 writes the header: it goes last, after all records
-    for (size_t k = g->shards.size(); k-- > 0;) {
-        const int rc = psim_checkpoint_write(g->shards[k], path, step);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
-}
-
-PSIM_API int psim_group_checkpoint_read(psim_group *g, const char *path, uint64_t *step_out)
-{
-    if (!g) return fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_checkpoint_read(h, path, step_out);
-        if (rc != PSIM_OK) return rc;
-    }
     return PSIM_OK;
 }
 

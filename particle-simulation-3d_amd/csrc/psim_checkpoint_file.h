@@ -17,7 +17,7 @@
 #include "psim.h"
 
 // Provided by the includer: records the message of a failure and returns `code`.
-int psim_ckpt_fail(int code, const char *fmt, ...);
+int psim_fail(int code, const char *fmt, ...);
 
 namespace psim_ckpt {
 
@@ -37,7 +37,7 @@ inline int write_all(int fd, const void *buf, size_t bytes, uint64_t offset, con
     while (bytes) {
         const ssize_t w = pwrite(fd, p, bytes, (off_t)offset);
         if (w < 0 && errno == EINTR) continue;
-        if (w <= 0) return psim_ckpt_fail(PSIM_ERR_IO, "write to %s failed: %s", path, strerror(errno));
+        if (w <= 0) return psim_fail(PSIM_ERR_IO, "write to %s failed: %s", path, strerror(errno));
         p += w, bytes -= (size_t)w, offset += (uint64_t)w;
     }
     return PSIM_OK;
@@ -49,8 +49,8 @@ inline int read_all(int fd, void *buf, size_t bytes, uint64_t offset, const char
     while (bytes) {
         const ssize_t r = pread(fd, p, bytes, (off_t)offset);
         if (r < 0 && errno == EINTR) continue;
-        if (r < 0) return psim_ckpt_fail(PSIM_ERR_IO, "read from %s failed: %s", path, strerror(errno));
-        if (r == 0) return psim_ckpt_fail(PSIM_ERR_IO, "%s is shorter than its header says", path);
+        if (r < 0) return psim_fail(PSIM_ERR_IO, "read from %s failed: %s", path, strerror(errno));
+        if (r == 0) return psim_fail(PSIM_ERR_IO, "%s is shorter than its header says", path);
         p += r, bytes -= (size_t)r, offset += (uint64_t)r;
     }
     return PSIM_OK;
@@ -59,19 +59,19 @@ inline int read_all(int fd, void *buf, size_t bytes, uint64_t offset, const char
 inline int read_header(int fd, const char *path, psim_checkpoint_header *out)
 {
     struct stat st;
-    if (fstat(fd, &st) != 0) return psim_ckpt_fail(PSIM_ERR_IO, "stat of %s failed: %s", path, strerror(errno));
+    if (fstat(fd, &st) != 0) return psim_fail(PSIM_ERR_IO, "stat of %s failed: %s", path, strerror(errno));
     if ((uint64_t)st.st_size < sizeof(*out))
-        return psim_ckpt_fail(PSIM_ERR_IO, "%s is too short to be a checkpoint", path);
+        return psim_fail(PSIM_ERR_IO, "%s is too short to be a checkpoint", path);
     int rc = read_all(fd, out, sizeof(*out), 0, path);
     if (rc != PSIM_OK) return rc;
     if (memcmp(out->magic, kCheckpointMagic, sizeof(kCheckpointMagic)) != 0)
-        return psim_ckpt_fail(PSIM_ERR_IO, "%s is not a checkpoint (or its write was interrupted)", path);
+        return psim_fail(PSIM_ERR_IO, "%s is not a checkpoint (or its write was interrupted)", path);
     if (out->version != 1u || out->record_bytes != sizeof(psim_particle))
-        return psim_ckpt_fail(PSIM_ERR_IO, "%s: unsupported checkpoint version %u / record size %u", path,
+        return psim_fail(PSIM_ERR_IO, "%s: unsupported checkpoint version %u / record size %u", path,
                     out->version, out->record_bytes);
     const uint64_t room = ((uint64_t)st.st_size - sizeof(*out)) / sizeof(psim_particle);
     if (out->particle_count > room)
-        return psim_ckpt_fail(PSIM_ERR_IO, "%s holds %llu records, its header says %llu", path,
+        return psim_fail(PSIM_ERR_IO, "%s holds %llu records, its header says %llu", path,
                     (unsigned long long)room, (unsigned long long)out->particle_count);
     return PSIM_OK;
 }

@@ -14,7 +14,7 @@
 
 static char g_message[512];
 
-int psim_ckpt_fail(int code, const char *fmt, ...)
+int psim_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
