@@ -337,11 +337,24 @@ typedef struct psim_checkpoint_header {
  * page-locked memory while the file writes proceed.  A plain handle invalidates the header
  * first and writes it last, so an interrupted write leaves no valid file, and truncates the
  * file to its exact size.  A shard writes only its own records, at their place in the
- * whole-set file; the shard that owns particle 0 also writes the header, the one that owns
- * the last particle sets the file size: the caller runs every shard's call (any order, also
- * at the same time) and treats the file as complete when all have returned.  Data goes
- * through the page cache; no fsync.  Synchronous. */
+ * whole-set file, and never the header (`step` is ignored); the shard that owns the last
+ * particle sets the file size.  Shards -- in one process or many -- follow
+ *     psim_checkpoint_begin(path)            once, before any shard writes
+ *     psim_checkpoint_write(shard, path, 0)  every shard, any order, also at the same time
+ *     psim_checkpoint_commit(shard, path, step)   once, after every shard has returned
+ * with the caller's own barrier between the stages, so that a run interrupted anywhere
+ * before the commit leaves a file every reader rejects (psim_group_checkpoint_write does
+ * exactly this).  Data goes through the page cache; no fsync.  Synchronous. */
 int psim_checkpoint_write(psim_handle *h, const char *path, uint64_t step);
+
+/* Creates `path` when missing and invalidates its header.  Needs no device. */
+int psim_checkpoint_begin(const char *path);
+
+/* Writes the header of the whole set `h` belongs to (any of its shards, or a plain handle)
+ * after checking that the file has exactly the size of that set; fails with PSIM_ERR_IO
+ * when it has not, i.e. when the shard owning the last particle has not written.  Touches
+ * no device memory. */
+int psim_checkpoint_commit(const psim_handle *h, const char *path, uint64_t step);
 
 /* Restores the handle's particles from `path`: the header's particle_count must equal the
  * handle's whole-set count (so a file written by one sharding restores into any other).

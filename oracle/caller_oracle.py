@@ -2,7 +2,7 @@
 
 CPU restatement, in numpy float32 scalars, of how the reference application turns one
 frame of input into one SimParams (reference: src/app.rs:202-301 and :528-576, camera
-basis and motion src/camera.rs:72-82, 106-174).  It checks include/psim_caller.hpp.
+basis and motion src/camera.rs:72-82, 106-174).  It checks tests/cpp/psim_caller.hpp.
 cos/sin/tan go through the C library's cosf/sinf/tanf, which is what Rust's f32::cos etc.
 and C++'s std::cos(float) call on this platform.
 

@@ -162,6 +162,8 @@ ABI = {
     "psim_device_soa": (c_int, [_P, POINTER(SoaView)]),
     "psim_checksum": (c_int, [_P, POINTER(c_uint64)]),
     "psim_checkpoint_write": (c_int, [_P, c_char_p, c_uint64]),
+    "psim_checkpoint_begin": (c_int, [c_char_p]),
+    "psim_checkpoint_commit": (c_int, [_P, c_char_p, c_uint64]),
     "psim_checkpoint_read": (c_int, [_P, c_char_p, POINTER(c_uint64)]),
     "psim_checkpoint_info": (c_int, [c_char_p, POINTER(CheckpointHeader)]),
     "psim_group_create": (c_int, [POINTER(_P), c_uint64, POINTER(c_int), c_uint32, c_int]),
@@ -414,6 +416,11 @@ class HipParticleSimulation:
         its own records of the whole-set file)."""
         _check(self._lib.psim_checkpoint_write(self._h, os.fsencode(path), int(step)))
 
+    def commit_checkpoint(self, path, step=0):
+        """Shards only: writes the header once every shard has saved its records
+        (checkpoint_begin -> every shard's save_checkpoint -> commit_checkpoint)."""
+        _check(self._lib.psim_checkpoint_commit(self._h, os.fsencode(path), int(step)))
+
     def load_checkpoint(self, path):
         """Restores the particles from `path`; returns the stored step counter."""
         step = c_uint64(0)
@@ -578,6 +585,12 @@ def launch_shape(count, n_attractors=1):
     info = LaunchShapeInfo()
     _check(load_library().psim_launch_shape(count, n_attractors, byref(info)))
     return {name: getattr(info, name) for name, _ in LaunchShapeInfo._fields_}
+
+
+def checkpoint_begin(path):
+    """Creates `path` when missing and invalidates its header: the first stage of a
+    checkpoint written by several shards (no device needed)."""
+    _check(load_library().psim_checkpoint_begin(os.fsencode(path)))
 
 
 def checkpoint_info(path):

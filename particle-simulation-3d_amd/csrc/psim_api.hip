@@ -205,6 +205,29 @@ int allocate(psim_handle *h, uint32_t capacity)
     return PSIM_OK;
 }
 
+// What allocate() sets, so that a resize that fails later can put the old storage back.
+struct Storage {
+    void *slab;
+    psim::SoaPtrs soa;
+    uint64_t *checksum_dev;
+    psim_attractor *list_dev;
+    uint32_t capacity;
+};
+
+Storage storage_of(const psim_handle *h)
+{
+    return Storage{h->slab, h->soa, h->checksum_dev, h->list_dev, h->capacity};
+}
+
+void restore_storage(psim_handle *h, const Storage &st)
+{
+    h->slab = st.slab;
+    h->soa = st.soa;
+    h->checksum_dev = st.checksum_dev;
+    h->list_dev = st.list_dev;
+    h->capacity = st.capacity;
+}
+
 // The device-side AoS staging buffer: the whole set when it is small (<= 1 Mi particles),
 // otherwise the fixed 4 Mi-particle chunk.  Grows when a resize made the set larger.
 int ensure_stage(psim_handle *h)
@@ -254,10 +277,17 @@ int generate_range(psim_handle *h, int mode, const GenRange &r)
 // (possibly larger, sharded) set.
 int generate(psim_handle *h, int mode)
 {
+    // The reference's two generators index particles with u32 (mod.rs:150-188): a set of more
+    // than 2^32 particles (shards of a larger array) only has the synthetic uniform state.
+    if (h->global_count > 0xFFFFFFFFull && mode != PSIM_GEN_UNIFORM)
+        return fail(PSIM_ERR_INVALID, "the reference generators index particles with u32");
+    const int rc = generate_range(h, mode, GenRange{0u, h->count, h->global_first,
+                                                    h->global_count ? h->global_count
+                                                                    : (uint64_t)h->count});
+    if (rc != PSIM_OK) return rc;
     h->colours_changed = false;                  // every generator writes colour = initial colour
     h->watermark = h->count;
-    return generate_range(h, mode, GenRange{0u, h->count, h->global_first,
-                                            h->global_count ? h->global_count : (uint64_t)h->count});
+    return PSIM_OK;
 }
 
 int generate_impl(psim_handle *h, int mode, const GenRange &r)
@@ -622,8 +652,12 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
         HIP_TRY(psim::launch_update(s, count, *params, params->is_mouse_dragging > 0 ? 1 : 0,
                                     nullptr, nullptr, 0, t, stream));
     } else {
-        if (reinterpret_cast<uintptr_t>(px) & 3u)
-            return fail(PSIM_ERR_INVALID, "state arrays must be 4-byte aligned");
+        const uintptr_t all = reinterpret_cast<uintptr_t>(px) | reinterpret_cast<uintptr_t>(py) |
+                              reinterpret_cast<uintptr_t>(pz) | reinterpret_cast<uintptr_t>(vx) |
+                              reinterpret_cast<uintptr_t>(vy) | reinterpret_cast<uintptr_t>(vz) |
+                              (colours ? reinterpret_cast<uintptr_t>(color) : 0);
+        if (all & 3u)
+            return fail(PSIM_ERR_INVALID, "state and colour arrays must be 4-byte aligned");
         HIP_TRY(psim::launch_update_scalar(s, count, *params, 0, stream));
     }
     return PSIM_OK;
@@ -662,8 +696,8 @@ int resize_append(psim_handle *h, uint32_t new_count, int generation_mode)
     if (new_count > h->watermark) {
         const uint32_t additional = new_count - h->watermark;
         if (new_count > h->capacity) {               // cpu.rs:142-147: a larger buffer, state kept
+            const Storage before = storage_of(h);
             const psim::SoaPtrs old = h->soa;
-            void *old_slab = h->slab;
             int rc = allocate(h, round_capacity(new_count));
             if (rc != PSIM_OK) return rc;            // old storage stays valid
             const size_t w = h->watermark;
@@ -681,10 +715,14 @@ int resize_append(psim_handle *h, uint32_t new_count, int generation_mode)
                 e = hipMemcpyAsync(h->soa.padding, old.padding, w * 8, hipMemcpyDeviceToDevice,
                                    h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            (void)hipFree(old_slab);
-            if (e != hipSuccess)
+            if (e != hipSuccess) {                   // back to the old buffer, which is intact
+                (void)hipStreamSynchronize(h->stream);
+                (void)hipFree(h->slab);
+                restore_storage(h, before);
                 return fail(PSIM_ERR_HIP, "copying the particles into the larger buffer failed: %s",
                             hipGetErrorString(e));
+            }
+            (void)hipFree(before.slab);
         }
         const int rc = generate_range(h, generation_mode,
                                       GenRange{h->watermark, additional, 0, additional});
@@ -703,25 +741,48 @@ PSIM_API int psim_resize(psim_handle *h, uint32_t new_count, int generation_mode
     CHECK_HANDLE(h);
     if (generation_mode < PSIM_GEN_HOLLOW || generation_mode > PSIM_GEN_UNIFORM)
         return fail(PSIM_ERR_INVALID, "unknown generation mode %d", generation_mode);
-    h->generation_mode = generation_mode;            // compute.rs:153
-    if (new_count == h->count) return PSIM_OK;       // compute.rs:155-157
+    if (new_count == h->count) {                     // compute.rs:153-157: mode stored, no-op
+        h->generation_mode = generation_mode;
+        return PSIM_OK;
+    }
     if (new_count > kMaxParticles)
         return fail(PSIM_ERR_INVALID, "%u particles exceed the maximum of %u per handle",
                     new_count, kMaxParticles);
     if (h->global_count)
         return fail(PSIM_ERR_INVALID, "a shard cannot be resized; recreate the shards");
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->resize_semantics == PSIM_RESIZE_APPEND) return resize_append(h, new_count, generation_mode);
-    if (new_count > h->capacity) {                   // compute.rs:162-186: new buffer
-        void *old = h->slab;
+    // Count, watermark and generation mode change only once the new particles exist: a call
+    // that fails leaves the handle describing what its storage really holds.
+    if (h->resize_semantics == PSIM_RESIZE_APPEND) {
+        const int rc = resize_append(h, new_count, generation_mode);
+        if (rc == PSIM_OK) h->generation_mode = generation_mode;
+        return rc;
+    }
+    const Storage before = storage_of(h);
+    const uint32_t old_count = h->count;
+    const bool grown = new_count > h->capacity;
+    if (grown) {                                     // compute.rs:162-186: new buffer
         int rc = allocate(h, round_capacity(new_count));
         if (rc != PSIM_OK) return rc;                // old storage stays valid
-        (void)hipFree(old);
     }
     h->count = new_count;
     int rc = generate(h, generation_mode);           // compute.rs:160: all particles
-    if (rc != PSIM_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (rc == PSIM_OK && hipStreamSynchronize(h->stream) != hipSuccess)
+        rc = fail(PSIM_ERR_HIP, "generating the resized set failed: %s",
+                  hipGetErrorString(hipGetLastError()));
+    if (rc != PSIM_OK) {
+        // With a new buffer the old particles are untouched: back to them.  Without one the
+        // generators wrote in place; the old count then covers partly regenerated particles.
+        (void)hipStreamSynchronize(h->stream);
+        if (grown) {
+            (void)hipFree(h->slab);
+            restore_storage(h, before);
+        }
+        h->count = old_count;
+        return rc;
+    }
+    if (grown) (void)hipFree(before.slab);
+    h->generation_mode = generation_mode;
     return PSIM_OK;
 }
 
@@ -746,10 +807,10 @@ PSIM_API int psim_reset(psim_handle *h, int generation_mode)
     CHECK_HANDLE(h);
     if (generation_mode < PSIM_GEN_HOLLOW || generation_mode > PSIM_GEN_UNIFORM)
         return fail(PSIM_ERR_INVALID, "unknown generation mode %d", generation_mode);
-    h->generation_mode = generation_mode;            // compute.rs:212
     int rc = generate(h, generation_mode);           // compute.rs:213-215
     if (rc != PSIM_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    h->generation_mode = generation_mode;            // compute.rs:212
     return PSIM_OK;
 }
 
@@ -1171,7 +1232,7 @@ PSIM_API int psim_checkpoint_write(psim_handle *h, const char *path, uint64_t st
     if (rc != PSIM_OK) return rc;
     if (first + h->count == total && ftruncate(f.fd, (off_t)record_offset(total)) != 0)
         return fail(PSIM_ERR_IO, "cannot size %s: %s", path, strerror(errno));
-    if (first == 0) {
+    if (!shard) {                                   // shards: psim_checkpoint_commit, once all are in
         hdr = psim_ckpt::make_header(total, step, (uint32_t)h->generation_mode,
                                      (uint32_t)h->colour_semantics);
         rc = write_all(f.fd, &hdr, sizeof(hdr), 0, path);
@@ -1181,6 +1242,22 @@ PSIM_API int psim_checkpoint_write(psim_handle *h, const char *path, uint64_t st
     f.fd = -1;
     if (close(cfd) != 0) return fail(PSIM_ERR_IO, "closing %s failed: %s", path, strerror(errno));
     return PSIM_OK;
+}
+
+PSIM_API int psim_checkpoint_begin(const char *path)
+{
+    if (!path) return fail(PSIM_ERR_INVALID, "null path");
+    return psim_ckpt::begin_file(path);
+}
+
+PSIM_API int psim_checkpoint_commit(const psim_handle *h, const char *path, uint64_t step)
+{
+    if (!h) return fail(PSIM_ERR_INVALID, "null handle");
+    if (!path) return fail(PSIM_ERR_INVALID, "null path");
+    const uint64_t total = h->global_count ? h->global_count : (uint64_t)h->count;
+    return psim_ckpt::commit_file(path, psim_ckpt::make_header(total, step,
+                                                              (uint32_t)h->generation_mode,
+                                                              (uint32_t)h->colour_semantics));
 }
 
 PSIM_API int psim_checkpoint_read(psim_handle *h, const char *path, uint64_t *step_out)

@@ -97,6 +97,39 @@ inline psim_checkpoint_header make_header(uint64_t total, uint64_t step, uint32_
     return hdr;
 }
 
+// The begin / commit pair of a file written by several shards (possibly several processes):
+// begin leaves no valid header while records change; commit writes the header once every shard
+// has reported, after checking that the file really has room for `total` records.  A run that
+// is interrupted between the two leaves a file every reader rejects.
+inline int begin_file(const char *path)
+{
+    File f;
+    f.fd = open(path, O_WRONLY | O_CREAT | O_CLOEXEC, 0644);
+    if (f.fd < 0) return psim_fail(PSIM_ERR_IO, "cannot open %s for writing: %s", path, strerror(errno));
+    psim_checkpoint_header zero;
+    memset(&zero, 0, sizeof(zero));
+    return write_all(f.fd, &zero, sizeof(zero), 0, path);
+}
+
+inline int commit_file(const char *path, const psim_checkpoint_header &hdr)
+{
+    File f;
+    f.fd = open(path, O_WRONLY | O_CLOEXEC);
+    if (f.fd < 0) return psim_fail(PSIM_ERR_IO, "cannot open %s for writing: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(f.fd, &st) != 0) return psim_fail(PSIM_ERR_IO, "stat of %s failed: %s", path, strerror(errno));
+    if ((uint64_t)st.st_size != record_offset(hdr.particle_count))
+        return psim_fail(PSIM_ERR_IO, "%s is %llu bytes, a set of %llu particles needs %llu: a shard has not written",
+                         path, (unsigned long long)st.st_size, (unsigned long long)hdr.particle_count,
+                         (unsigned long long)record_offset(hdr.particle_count));
+    const int rc = write_all(f.fd, &hdr, sizeof(hdr), 0, path);
+    if (rc != PSIM_OK) return rc;
+    const int fd = f.fd;
+    f.fd = -1;
+    if (close(fd) != 0) return psim_fail(PSIM_ERR_IO, "closing %s failed: %s", path, strerror(errno));
+    return PSIM_OK;
+}
+
 }  // namespace psim_ckpt
 
 #endif  // PSIM_CHECKPOINT_FILE_H

@@ -206,22 +206,13 @@ PSIM_API int psim_group_checkpoint_write(psim_group *g, const char *path, uint64
 {
     if (!g) return psim_fail(PSIM_ERR_INVALID, "null group");
     if (!path) return psim_fail(PSIM_ERR_INVALID, "null path");
-    {                                            // no valid header while the records change
-        psim_ckpt::File f;
-        f.fd = open(path, O_WRONLY | O_CREAT | O_CLOEXEC, 0644);
-        if (f.fd < 0)
-            return psim_fail(PSIM_ERR_IO, "cannot open %s for writing: %s", path, strerror(errno));
-        psim_checkpoint_header zero;
-        memset(&zero, 0, sizeof(zero));
-        const int rc = psim_ckpt::write_all(f.fd, &zero, sizeof(zero), 0, path);
+    int rc = psim_checkpoint_begin(path);        // no valid header while the records change
+    if (rc != PSIM_OK) return rc;
+    for (psim_handle *h : g->shards) {
+        rc = psim_checkpoint_write(h, path, step);
         if (rc != PSIM_OK) return rc;
     }
-    // the shard that owns particle 0 writes the header: it goes last, after all records
-    for (size_t k = g->shards.size(); k-- > 0;) {
-        const int rc = psim_checkpoint_write(g->shards[k], path, step);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
+    return psim_checkpoint_commit(g->shards[0], path, step);
 }
 
 PSIM_API int psim_group_checkpoint_read(psim_group *g, const char *path, uint64_t *step_out)

@@ -86,6 +86,31 @@ int main(int argc, char **argv)
                          path.c_str()) == PSIM_ERR_IO);
     }
 
+    // begin / commit of a file written by several shards: no valid header from begin until
+    // commit, and no commit while the file has not reached the size of the set
+    {
+        psim_checkpoint_header got;
+        REQUIRE(begin_file(path.c_str()) == PSIM_OK);                // over the valid file above
+        REQUIRE(header_status(path, &got) == PSIM_ERR_IO);           // records intact, header gone
+        REQUIRE(commit_file(path.c_str(), make_header(total, 78, 0, 0)) == PSIM_OK);
+        REQUIRE(header_status(path, &got) == PSIM_OK && got.step == 78);
+        const std::string part = dir + "/partial.ckp";
+        std::remove(part.c_str());
+        REQUIRE(begin_file(part.c_str()) == PSIM_OK);
+        {
+            File f;
+            f.fd = open_rw(part);
+            REQUIRE(f.fd >= 0);
+            REQUIRE(write_all(f.fd, records.data(), 500 * sizeof(psim_particle), record_offset(0),
+                              part.c_str()) == PSIM_OK);             // the second shard never wrote
+        }
+        REQUIRE(commit_file(part.c_str(), make_header(total, 1, 0, 0)) == PSIM_ERR_IO);
+        REQUIRE(std::string(g_message).find("has not written") != std::string::npos);
+        REQUIRE(header_status(part, &got) == PSIM_ERR_IO);
+        REQUIRE(commit_file((dir + "/missing.ckp").c_str(), make_header(0, 0, 0, 0)) == PSIM_ERR_IO);
+        REQUIRE(commit_file(path.c_str(), make_header(total, 77, PSIM_GEN_FILLED, PSIM_COLOR_RESET)) == PSIM_OK);
+    }
+
     // broken files
     const std::string bad = dir + "/bad.ckp";
     auto write_bad = [&](const psim_checkpoint_header &h, uint64_t n_records, size_t header_bytes) {

@@ -1,4 +1,4 @@
-// psim_caller.hpp -- host-side mirror of the code that feeds the update path in the
+// psim_caller.hpp -- replay / test infrastructure, not part of the library boundary: host-side mirror of the code that feeds the update path in the
 // reference application: how one frame's input becomes one SimParams.
 //
 //   * the camera basis and its keyboard / pointer motion  (reference: src/camera.rs:106-174,

@@ -1,5 +1,5 @@
 // session_replay.cpp -- replays a recorded input session through the caller-side mirror
-// (include/psim_caller.hpp; reference: src/app.rs:202-301, 528-576) and, when built with
+// (tests/cpp/psim_caller.hpp; reference: src/app.rs:202-301, 528-576) and, when built with
 // PSIM_WITH_DEVICE, feeds the resulting SimParams stream to the simulation.
 //
 //   caller_params  <inputs> <ui> <params_out>                      (no GPU, links nothing)

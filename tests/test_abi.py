@@ -38,7 +38,7 @@ def test_python_binding_covers_every_declared_symbol():
 
 
 def test_header_is_plain_c_and_links(tmp_path):
-    """include/psim.h compiles as C99 (and as C++ through psim.hpp / psim_caller.hpp), the
+    """include/psim.h compiles as C99 (and as C++ through psim.hpp; the replay helper tests/cpp/psim_caller.hpp on top of it), the
     record sizes are the reference's (mod.rs:52-67, 86-98), and a C program links against the
     library with nothing but the header."""
     import subprocess
@@ -76,7 +76,8 @@ int main(void) {
                    'int main() { psim::CallerState s; psim::FrameInput in{}; in.screen_width = 1;'
                    ' in.screen_height = 1; return s.frame(in).damping == 0.99f ? 0 : 1; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
-                           "-I", os.path.join(T.ROOT, "include"), str(cpp)])
+                           "-I", os.path.join(T.ROOT, "include"),
+                           "-I", os.path.join(T.ROOT, "tests", "cpp"), str(cpp)])
 
 
 def test_library_exports_nothing_else_public():

@@ -1,5 +1,5 @@
 """The caller side of the path: one frame of input -> one SimParams
-(include/psim_caller.hpp, mirroring src/app.rs:202-301, 528-576 and src/camera.rs).
+(tests/cpp/psim_caller.hpp, mirroring src/app.rs:202-301, 528-576 and src/camera.rs).
 A seeded synthetic session (cursor drags, camera rotation and flight, scroll-wheel depth,
 window resizes, slider changes, pauses) goes through the C++ mirror and through the numpy
 restatement in oracle/caller_oracle.py; the SimParams streams must agree bit for bit.  On

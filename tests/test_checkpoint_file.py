@@ -95,6 +95,26 @@ def test_null_arguments():
     assert lib.psim_checkpoint_info(b"/tmp/x", None) == 1
     assert lib.psim_checkpoint_write(None, b"/tmp/x", 0) == 1
     assert lib.psim_checkpoint_read(None, b"/tmp/x", None) == 1
+    assert lib.psim_checkpoint_begin(None) == 1
+    assert lib.psim_checkpoint_commit(None, b"/tmp/x", 0) == 1
+
+
+def test_begin_invalidates_a_valid_file(tmp_path):
+    """psim_checkpoint_begin needs no device: the records stay, the header goes."""
+    path = tmp_path / "state.ckp"
+    write_file(path, 10, sample_records(10))
+    assert psim.checkpoint_info(path)["particle_count"] == 10
+    psim.checkpoint_begin(path)
+    with pytest.raises(psim.PsimError) as e:
+        psim.checkpoint_info(path)
+    assert e.value.code == 5
+    assert path.stat().st_size == 64 + 64 * 10
+    fresh = tmp_path / "fresh.ckp"
+    psim.checkpoint_begin(fresh)
+    assert fresh.stat().st_size == 64
+    with pytest.raises(psim.PsimError) as e:
+        psim.checkpoint_begin(tmp_path / "no_such_dir" / "x.ckp")
+    assert e.value.code == 5
 
 
 def test_file_helpers_under_the_host_sanitizers(tmp_path):

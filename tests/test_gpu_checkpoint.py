@@ -89,8 +89,14 @@ def test_shards_write_one_file_and_any_sharding_restores_it(tmp_path):
     try:
         for s in shards:
             s.update(colour_params(2))
-        for s in reversed(shards):                       # any order; header comes last here
-            s.save_checkpoint(path, step=1)
+        psim.checkpoint_begin(path)
+        for k, s in enumerate(reversed(shards)):         # any order
+            s.save_checkpoint(path)
+            with pytest.raises(psim.PsimError):          # no shard wrote a header
+                psim.checkpoint_info(path)
+            if k == 1:                                   # the last particle's owner is in, not all
+                assert path.stat().st_size == 64 + 64 * total
+        shards[2].commit_checkpoint(path, step=1)        # any shard may commit
         pieces = [s.download_aos() for s in shards]
     finally:
         for s in shards:
@@ -128,3 +134,35 @@ def test_restored_colours_follow_the_reset_rule(tmp_path):
         sim.update(colour_params(0))
         after = sim.download_aos()
         assert after["color"].tobytes() == after["initial_color"].tobytes()
+
+
+def test_an_interrupted_sharded_write_leaves_no_valid_file(tmp_path):
+    """Overwriting a valid checkpoint of the same size shard by shard: between begin and
+    commit the file is rejected; a commit before the last particle's owner has written fails."""
+    path = tmp_path / "whole.ckp"
+    total = 10_000
+    with Sim.new(total, psim.GEN_FILLED) as whole:
+        whole.save_checkpoint(path, step=5)
+    assert psim.checkpoint_info(path)["step"] == 5
+    with Sim.new_shard(6000, 0, total, psim.GEN_UNIFORM) as a, \
+            Sim.new_shard(4000, 6000, total, psim.GEN_UNIFORM) as b:
+        psim.checkpoint_begin(path)
+        a.save_checkpoint(path)                          # the run "dies" here: b never writes
+        with pytest.raises(psim.PsimError) as e:
+            psim.checkpoint_info(path)
+        assert e.value.code == 5
+        with Sim.new(total, psim.GEN_HOLLOW) as reader:
+            with pytest.raises(psim.PsimError):
+                reader.load_checkpoint(path)
+        # a fresh file, where the size tells that a shard is missing
+        fresh = tmp_path / "fresh.ckp"
+        psim.checkpoint_begin(fresh)
+        a.save_checkpoint(fresh)
+        with pytest.raises(psim.PsimError) as e:
+            a.commit_checkpoint(fresh, step=1)
+        assert e.value.code == 5 and "has not written" in str(e.value)
+        b.save_checkpoint(fresh)
+        b.commit_checkpoint(fresh, step=2)
+        assert psim.checkpoint_info(fresh)["step"] == 2
+        want = np.concatenate([a.download_aos(), b.download_aos()])
+    assert psim.read_checkpoint_records(fresh).tobytes() == want.tobytes()

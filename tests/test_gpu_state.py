@@ -289,6 +289,26 @@ def test_uniform_shard_beyond_u32_indices():
                                  "shard past 2^32")
 
 
+def test_reset_of_a_set_beyond_u32_keeps_to_the_uniform_state():
+    """The reference's generators index with u32 (mod.rs:150-188): a shard of a set of more
+    than 2^32 particles refuses them on reset as it does on creation, and stays as it was."""
+    first, total = 5_000_000_000, 8_000_000_000
+    lib = psim.load_library()
+    h = ctypes.c_void_p()
+    assert lib.psim_create_shard(ctypes.byref(h), 1000, first, total, psim.GEN_HOLLOW, 0) == 1
+    with Sim.new_shard(1000, first, total, psim.GEN_UNIFORM) as shard:
+        shard.update(T.bench_params(gravity=1.0))
+        before = shard.download_aos()
+        for mode in (psim.GEN_HOLLOW, psim.GEN_FILLED):
+            with pytest.raises(psim.PsimError, match="u32") as e:
+                shard.reset(mode)
+            assert e.value.code == 1
+        assert shard.download_aos().tobytes() == before.tobytes()
+        shard.reset(psim.GEN_UNIFORM)
+        T.assert_particles_equal(shard.download_aos(), T.oracle_gen_uniform_aos(first, 1000),
+                                 "reset shard past 2^32")
+
+
 # ---- errors -----------------------------------------------------------------------------------------
 
 def test_error_codes():
