@@ -190,6 +190,19 @@ int psim_update_multi(psim_handle *h, const psim_sim_params *params,
 int psim_update_multi_host(psim_handle *h, const psim_sim_params *params,
                            const psim_attractor *attractors_host, uint32_t n_attractors);
 
+/* psim_update_multi_host for callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * The call allocates nothing, on the host or the device, and uses no copy engine: the list
+ * (at most PSIM_MAX_ATTRACTORS records; more is PSIM_ERR_INVALID) is written by small kernels
+ * that carry it in their arguments into a static device array of the library -- 2 KiB that
+ * every GPU the library runs on holds until the process ends -- and the update kernel stages
+ * it from there into LDS.  The result is that of psim_update_multi_host, bit for bit.  All
+ * handles on one GPU share that array: calls on one stream follow each other safely, calls
+ * that overlap on different streams of one GPU race for it.  Asynchronous; the host list is
+ * copied before returning. */
+int psim_update_multi_host_noalloc(psim_handle *h, const psim_sim_params *params,
+                                   const psim_attractor *attractors_host, uint32_t n_attractors);
+
 /* Applies n_steps consecutive updates, params_host[0] first, with the state crossing
  * HBM once per 64 steps instead of once per step: each lane loads its particles,
  * steps them in registers with one parameter set after the other, and stores them.

@@ -137,6 +137,7 @@ ABI = {
     "psim_update_batch": (c_int, [_P, POINTER(SimParams), c_uint32]),
     "psim_update_multi": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
     "psim_update_multi_host": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
+    "psim_update_multi_host_noalloc": (c_int, [_P, POINTER(SimParams), _P, c_uint32]),
     "psim_update_soa": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_uint32, POINTER(SimParams), _P]),
     "psim_store_attractor": (c_int, [_P, _P, _P]),
     "psim_sync": (c_int, [_P]),
@@ -302,6 +303,12 @@ class HipParticleSimulation:
         arr = _as_attractors(attractors)
         _check(self._lib.psim_update_multi_host(self._h, byref(params),
                                                 arr.ctypes.data_as(c_void_p), len(arr)))
+
+    def update_multi_noalloc(self, params, attractors):
+        """update_multi through the library's static device list: allocates nothing."""
+        arr = _as_attractors(attractors)
+        _check(self._lib.psim_update_multi_host_noalloc(self._h, byref(params),
+                                                        arr.ctypes.data_as(c_void_p), len(arr)))
 
     def store_attractor(self, dst_device_ptr, attractor, stream=None):
         """Writes one attractor record to device memory on `stream` (default: the

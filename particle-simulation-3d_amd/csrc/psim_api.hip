@@ -151,6 +151,7 @@ struct psim_handle {
     uint64_t *checksum_dev = nullptr;          // 8 x u64 inside the slab
     psim_attractor *list_dev = nullptr;        // kListSlots attractor lists inside the slab
     psim_attractor *list_host = nullptr;       // their page-locked staging
+    psim_attractor *static_list = nullptr;     // this device's copy of the library's static list
     hipEvent_t list_copied[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t list_next = 0;
     psim_particle *aos_stage = nullptr;        // lazily allocated AoS staging chunk
@@ -448,7 +449,11 @@ int create_impl(psim_handle **out, uint32_t count, uint64_t global_first, uint64
         rc = fail(PSIM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     } else {
         h->stream = h->own_stream;
-        rc = allocate(h, round_capacity(count));
+        // set-up for psim_update_multi_host_noalloc, which may not do it itself
+        e = psim::static_list_address(device_id, &h->static_list);
+        if (e != hipSuccess)
+            rc = fail(PSIM_ERR_HIP, "address of the static attractor list: %s", hipGetErrorString(e));
+        if (rc == PSIM_OK) rc = allocate(h, round_capacity(count));
         if (rc == PSIM_OK) rc = generate(h, generation_mode);
         if (rc == PSIM_OK) {
             e = hipStreamSynchronize(h->stream);
@@ -621,6 +626,27 @@ PSIM_API int psim_update_multi_host(psim_handle *h, const psim_sim_params *param
     HIP_TRY(psim::launch_update(h->soa, h->count, *params, force, nullptr, attractors_host,
                                 n_attractors, tuning_for(h->count, n_attractors, h->overrides),
                                 h->stream));
+    return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
+}
+
+PSIM_API int psim_update_multi_host_noalloc(psim_handle *h, const psim_sim_params *params,
+                                            const psim_attractor *attractors_host,
+                                            uint32_t n_attractors)
+{
+    CHECK_HANDLE(h);
+    if (!params) return fail(PSIM_ERR_INVALID, "null params");
+    if (n_attractors > PSIM_MAX_ATTRACTORS)
+        return fail(PSIM_ERR_INVALID,
+                    "%u attractors exceed the %u records of the static device list", n_attractors,
+                    PSIM_MAX_ATTRACTORS);
+    if (n_attractors && !attractors_host) return fail(PSIM_ERR_INVALID, "null attractor list");
+    if (!h->static_list) return fail(PSIM_ERR_HIP, "the static attractor list has no address");
+    // Every record the kernel reads is written first, in stream order, so nothing of an
+    // earlier, longer list is seen; nothing has to start at zero.
+    HIP_TRY(psim::launch_store_attractors(h->static_list, attractors_host, n_attractors, h->stream));
+    HIP_TRY(psim::launch_update(h->soa, h->count, *params, n_attractors ? 2 : 0, h->static_list,
+                                nullptr, n_attractors,
+                                tuning_for(h->count, n_attractors, h->overrides), h->stream));
     return settle_colours(h, params->color_mode, is_colour_mode(params->color_mode));
 }
 

@@ -63,6 +63,15 @@ hipError_t launch_update_scalar(const SoaPtrs &s, uint32_t n, const psim_sim_par
 hipError_t launch_store_attractor(psim_attractor *dst, const psim_attractor &value,
                                   hipStream_t stream);
 
+// The address, on `device` (which must be current), of the library's static device array
+// of PSIM_MAX_ATTRACTORS attractor records; asked once per device and remembered.
+hipError_t static_list_address(int device, psim_attractor **out);
+
+// Writes `count` records from host memory into device memory at `dst`, carried in the
+// arguments of ceil(count / 8) small kernels: no copy engine, no page-locked staging.
+hipError_t launch_store_attractors(psim_attractor *dst, const psim_attractor *values_host,
+                                   uint32_t count, hipStream_t stream);
+
 hipError_t launch_gen_uniform(const SoaPtrs &s, uint32_t n, uint64_t global_first, uint64_t seed,
                               hipStream_t stream);
 

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "psim_kernels.h"
@@ -944,6 +945,64 @@ hipError_t launch_store_attractor(psim_attractor *dst, const psim_attractor &val
 {
     hipLaunchKernelGGL(store_attractor_kernel, dim3(1), dim3(64), 0, stream, dst, value);
     return hipGetLastError();
+}
+
+// ---- attractor list in a static device array (the entry point that allocates nothing) ----
+//
+// `scratch` is the device-side staging of a host attractor list for callers that may not
+// allocate: 64 records = 2 KiB, held by every GPU the library runs on until the process
+// ends.  In host code the array's name is only a stand-in; the address each GPU holds its
+// copy at comes from hipGetSymbolAddress, once per device, and that pointer is what every
+// kernel argument below uses.
+static __device__ __align__(256) psim_attractor scratch[PSIM_MAX_ATTRACTORS];
+
+#define PSIM_MAX_DEVICES 64
+static psim_attractor *g_static_list[PSIM_MAX_DEVICES];   // by device ordinal, null = not asked yet
+static std::mutex g_static_list_lock;
+
+hipError_t static_list_address(int device, psim_attractor **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= PSIM_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(g_static_list_lock);
+    if (!g_static_list[device]) {
+        int current = -1;
+        hipError_t e = hipGetDevice(&current);
+        if (e != hipSuccess) return e;
+        if (current != device) return hipErrorInvalidDevice;   // the caller makes it current
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_static_list[device] = static_cast<psim_attractor *>(ptr);
+    }
+    *out = g_static_list[device];
+    return hipSuccess;
+}
+
+// Up to PSIM_KERNARG_ATTRACTORS records travel in the kernel arguments; one lane per word.
+__global__ void store_attractors_kernel(psim_attractor *dst, KernargAttractors ka, uint32_t count)
+{
+    constexpr uint32_t kWords = sizeof(psim_attractor) / 4u;
+    static_assert(PSIM_KERNARG_ATTRACTORS * kWords <= 64u, "one wave covers a chunk");
+    const uint32_t w = threadIdx.x;
+    if (blockIdx.x == 0 && w < count * kWords)
+        reinterpret_cast<uint32_t *>(dst)[w] = reinterpret_cast<const uint32_t *>(ka.a)[w];
+}
+
+hipError_t launch_store_attractors(psim_attractor *dst, const psim_attractor *values_host,
+                                   uint32_t count, hipStream_t stream)
+{
+    for (uint32_t done = 0; done < count; done += PSIM_KERNARG_ATTRACTORS) {
+        const uint32_t m = (count - done) < PSIM_KERNARG_ATTRACTORS ? (count - done)
+                                                                    : PSIM_KERNARG_ATTRACTORS;
+        KernargAttractors ka;
+        memset(&ka, 0, sizeof(ka));
+        memcpy(ka.a, values_host + done, m * sizeof(psim_attractor));
+        hipLaunchKernelGGL(store_attractors_kernel, dim3(1), dim3(64), 0, stream, dst + done, ka, m);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---- synthetic uniform state -----------------------------------------------
