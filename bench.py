@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the particle-update hot path on MI355X.
 
-A step is one update (one kernel launch) of this rank's particle shard.  At N = 1 the
-workload is the headline configuration: 100 M particles, single attractor, fp32,
-synthetic uniform-random state generated on the device.  With N > 1 every rank holds its
-own 100 M-particle shard of an N x 100 M array (weak scaling); the single-attractor path
-needs no communication, so torch.distributed is used only for the barriers and the
-max-over-ranks of the timing.
+A step is one update (one kernel launch) of this rank's particle shard.  The default, and
+the workload the headline metric is quoted on, is `--config 3`: 100 M particles per GPU,
+single attractor, fp32, synthetic uniform-random state generated on the device.  With N > 1
+every rank holds its own shard (weak scaling: the per-GPU count is fixed; `--scaling strong`:
+the total is fixed and divided).  The single-attractor path needs no communication, so
+torch.distributed is used only for the barriers and the max-over-ranks of the timing.
+
+  --config 2   10 M particles, single attractor (fits the Infinity Cache: cache-assisted)
+  --config 3   100 M particles per GPU, single attractor            (headline, default)
+  --config 4   1 B particles over 8 GPUs = 125 M per GPU, single attractor, no collective
+  --config 5   50 M particles over 8 GPUs = 6.25 M per GPU, one moving attractor per rank,
+               all-gathered every step over RCCL by the library's own exchange
 
 Prints ONE JSON line on rank 0: whole-job particle-updates/s over the timed steps, plus
 `roofline` (algorithmic bytes per launch / HIP-event launch duration against the HBM peak,
-and the HBM traffic measured with rocprofv3 counters when a summary for this size is
-present under profiles/) and, at N = 1, `cpu_baseline` (the CPU restatement of the
-reference's update timed on the host cores).
+and the HBM traffic measured with rocprofv3 counters when the committed summary under
+profiles/ was taken from this very build) and, at N = 1, `cpu_baseline` (the CPU restatement
+of the reference's update timed on the host cores).  At N > 1 the single-attractor
+configurations append `exchange_check`: a short run of the config-5 step over all ranks,
+outside the timed region, so that one multi-GPU run also shows what the collective delivers
+and costs.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -28,6 +38,18 @@ sys.path.insert(0, ROOT)
 
 ALGORITHMIC_BYTES_PER_UPDATE = 48      # 6 fp32 read + 6 fp32 written, colour mode 0
 HBM_PEAK_GBPS = 8000.0                 # MI355X HBM3E datasheet peak
+KERNEL_SOURCES = ("psim_kernels.hip", "psim_kernels.h", "psim_threshold.h", "Makefile")
+
+# name, particles per GPU as written (the 8-GPU configurations divided by 8), total when the
+# particle count is held fixed instead (--scaling strong), workload
+CONFIGS = {
+    2: ("configs[1]: 10M particles, single attractor", 10_000_000, 10_000_000, "single"),
+    3: ("configs[2]: 100M particles, single attractor", 100_000_000, 100_000_000, "single"),
+    4: ("configs[3]: 1B particles over 8 GPUs (125M per GPU), single attractor, no collective",
+        125_000_000, 1_000_000_000, "single"),
+    5: ("configs[4]: 50M particles over 8 GPUs (6.25M per GPU), one moving attractor per rank, "
+        "RCCL all-gather of attractor state every step", 6_250_000, 50_000_000, "multi"),
+}
 
 
 def parse_args():
@@ -35,18 +57,26 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--particles", type=int, default=100_000_000,
-                    help="particles per GPU (default: the 100 M headline configuration)")
-    ap.add_argument("--workload", choices=["single", "multi"], default="single",
-                    help="single: one attractor, no communication (headline); "
-                         "multi: one moving attractor per rank, all-gathered every step")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
+                    help="which configuration of the baseline to run (default 3: 100 M per GPU)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the per-GPU particle count is fixed; strong: the total is")
+    ap.add_argument("--particles", type=int, default=None,
+                    help="particles per GPU (weak) or in total (strong); overrides --config's count")
+    ap.add_argument("--workload", choices=["single", "multi"], default=None,
+                    help="single: one attractor, no communication; multi: one moving attractor "
+                         "per rank, all-gathered every step (default: what --config says)")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
+                    help="multi workload: the library's own RCCL exchange (psim_exchange_*) or "
+                         "torch.distributed's all_gather_into_tensor")
     ap.add_argument("--lookahead", type=int, default=1,
-                    help="multi workload: steps of attractor state exchanged per all-gather "
-                         "(1 = one collective per step)")
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000,
-                    help="particles of the same workload stepped by the CPU baseline")
+                    help="multi workload with --exchange torch: steps of attractor state "
+                         "exchanged per all-gather (1 = one collective per step)")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="particles stepped by the CPU baseline (default: the GPU's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange-check", action="store_true")
     return ap.parse_args()
 
 
@@ -75,22 +105,111 @@ def cpu_baseline(sample, seconds):
         "unit": "particle-updates/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{sample} particles (first {sample} of the same synthetic state, AoS 64 B) x "
+        "sample": f"{sample} particles (the same synthetic state from particle 0 on, AoS 64 B) x "
                   f"{steps} steps in {dt:.2f} s; update loop only, no upload copy",
     }
 
 
-def load_traffic(particles):
-    """HBM bytes per launch from the committed PMC summary, if it covers this size."""
+def host_memory_allows(particles):
+    """The CPU leg holds `particles` 64-byte records; keep well inside the free memory."""
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return particles * 64 * 2 < int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return particles <= 20_000_000
+
+
+def sha256_of(paths):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            for block in iter(lambda: f.read(1 << 20), b""):
+                h.update(block)
+    return h.hexdigest()
+
+
+def build_identity(psim):
+    csrc = os.path.dirname(psim.LIBRARY_PATH)
+    return {"library_sha256": sha256_of([psim.LIBRARY_PATH]),
+            "kernel_sources_sha256": sha256_of([os.path.join(csrc, n) for n in KERNEL_SOURCES])}
+
+
+def load_traffic(particles, identity):
+    """HBM bytes per launch from the committed counter summary, when it was taken at this
+    size from this build: the same library file, or one built from the same kernel sources."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    info = {"traffic": None, "traffic_profiled_git_sha": None, "traffic_build_match": "no summary"}
     try:
         with open(path) as f:
             s = json.load(f)
-        if int(s.get("particles", -1)) == particles:
-            return float(s["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    except (OSError, ValueError):
+        return info
+    info["traffic_profiled_git_sha"] = s.get("git_sha")
+    if int(s.get("particles", -1)) != particles:
+        info["traffic_build_match"] = f"summary is for {s.get('particles')} particles"
+    elif s.get("library_sha256") == identity["library_sha256"]:
+        info["traffic_build_match"] = "library"
+    elif s.get("kernel_sources_sha256") == identity["kernel_sources_sha256"]:
+        info["traffic_build_match"] = "kernel sources"
+    else:
+        info["traffic_build_match"] = "none: profiled build differs from this one"
+    if info["traffic_build_match"] in ("library", "kernel sources"):
+        info["traffic"] = float(s["hbm_bytes_per_launch"])
+    return info
+
+
+def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, steps=200, warmup=20):
+    """The config-5 step (6.25 M particles per rank, one moving attractor per rank, RCCL
+    all-gather every step through psim_exchange_*) over all ranks, untimed by the headline:
+    what the collective delivers (bit for bit against the closed-form paths) and what a step
+    costs against the same kernel fed from a host list."""
+    import numpy as np
+    n = 6_250_000
+    ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        ident.copy_(torch.frombuffer(bytearray(psim.exchange_unique_id()), dtype=torch.uint8))
+    dist.broadcast(ident, 0)
+    runner = par.NativeMultiAttractorRunner(n, rank, world, local_rank, params,
+                                            bytes(ident.cpu().numpy().tobytes()))
+    for _ in range(warmup):
+        runner.step()
+    runner.finish()
+    dist.barrier(device_ids=[local_rank])
+    runner.sim.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step()
+    device_ms = runner.sim.timer_stop()
+    runner.finish()
+    wall = time.perf_counter() - t0
+    last = warmup + steps - 1
+    ok = runner.exchange.last_list().tobytes() == par.attractors_at(last, world).tobytes()
+    # the same kernel without the exchange: the list handed over by the host
+    table = par.attractors_at(last, world)
+    for _ in range(warmup):
+        runner.sim.update_multi(params, table)
+    runner.sim.sync()
+    runner.sim.timer_start()
+    for _ in range(steps):
+        runner.sim.update_multi(params, table)
+    kernel_ms = runner.sim.timer_stop()
+    runner.close()
+    t = torch.tensor([wall / steps * 1e6, device_ms / steps * 1e3, kernel_ms / steps * 1e3,
+                      0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    w, d, k, bad = (float(v) for v in t.tolist())
+    return {
+        "workload": f"{n} particles per GPU, {world} moving attractors, psim_exchange_step "
+                    f"(RCCL all-gather of 32 B per rank, double-buffered) x {steps} steps",
+        "lists_match_closed_form": bad == 0.0,
+        "us_per_step_wall": w,
+        "us_per_step_device": d,
+        "us_per_step_kernel_only": k,
+        "aggregation": "max over ranks",
+    }
 
 
 def main():
@@ -111,6 +230,9 @@ def main():
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this benchmark has no CPU path")
+    config_name, per_gpu, fixed_total, workload = CONFIGS[args.config]
+    if args.workload:
+        workload = args.workload
     # PSIM_BENCH_REHEARSAL=1 (tests only): several ranks share the GPUs that exist and talk
     # over gloo, so the N > 1 control flow can be run on a one-GPU machine.  The numbers of
     # such a run mean nothing.
@@ -119,7 +241,8 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the process group is used even for one rank
-    distributed = world > 1 or args.workload == "multi" or "RANK" in os.environ
+    distributed = world > 1 or (workload == "multi" and args.exchange == "torch") \
+        or "RANK" in os.environ
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -138,18 +261,40 @@ def main():
                 dist.barrier(device_ids=[local_rank])
 
     psim = importlib.import_module("particle-simulation-3d_amd")
-    n = args.particles
+    par = importlib.import_module("particle-simulation-3d_amd.parallel")
+    # this rank's shard: [first, first + n) of `total`
+    if args.scaling == "strong":
+        total = args.particles if args.particles is not None else fixed_total
+        first, n = par.shard_range(total, rank, world)
+    else:
+        n = args.particles if args.particles is not None else per_gpu
+        total, first = world * n, rank * n
     params = psim.SimParams(delta_time=0.016, gravity=0.0, color_mode=0, mouse_force=5.0,
                             mouse_radius=10.0, is_mouse_dragging=1, damping=0.99,
                             max_dist_for_color=50.0, mouse_position=(0.0, 0.0, 48.0))
 
-    if args.workload == "multi":
-        par = importlib.import_module("particle-simulation-3d_amd.parallel")
-        runner = par.MultiAttractorRunner(n, rank, world, local_rank, params,
-                                          lookahead=args.lookahead)
+    if workload == "multi":
+        if args.exchange == "native":
+            if rehearsal:
+                raise SystemExit("RCCL cannot put two ranks on one GPU: no rehearsal of the exchange")
+            if world > 1:
+                ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    ident.copy_(torch.frombuffer(bytearray(psim.exchange_unique_id()),
+                                                 dtype=torch.uint8))
+                dist.broadcast(ident, 0)
+                unique_id = ident.cpu().numpy().tobytes()
+            else:
+                unique_id = psim.exchange_unique_id()
+            runner = par.NativeMultiAttractorRunner(n, rank, world, local_rank, params, unique_id,
+                                                    first=first, total=total)
+        else:
+            runner = par.MultiAttractorRunner(n, rank, world, local_rank, params,
+                                              lookahead=args.lookahead, first=first, total=total)
         step, finish, sim = runner.step, runner.finish, runner.sim
     else:
-        sim = psim.HipParticleSimulation.new_shard(n, rank * n, world * n, psim.GEN_UNIFORM,
+        runner = None
+        sim = psim.HipParticleSimulation.new_shard(n, first, total, psim.GEN_UNIFORM,
                                                    device_id=local_rank)
         step = lambda: sim.update(params)      # noqa: E731
         finish = lambda: None                  # noqa: E731
@@ -165,21 +310,52 @@ def main():
     sim.timer_start()
     for _ in range(args.steps):
         step()
-    finish()
     device_ms = sim.timer_stop()
+    finish()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed = time.perf_counter() - t0
+    per_rank = [[own_elapsed, device_ms, float(n)]]
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dev = "cpu" if rehearsal else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=dev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = [[float(v) for v in r.tolist()] for r in everyone]
     barrier()
 
+    check = None
+    if world > 1 and workload == "single" and not rehearsal and not args.no_exchange_check:
+        sim.close()
+        sim = None
+        check = exchange_check(psim, par, torch, dist, rank, world, local_rank, params)
+
     if rank == 0:
-        total_updates = world * n * args.steps
-        launch_s = device_ms / 1e3 / args.steps
-        bytes_per_launch = ALGORITHMIC_BYTES_PER_UPDATE * n
-        achieved = bytes_per_launch / launch_s / 1e9
+        total_updates = total * args.steps
+        wall_ms = [r[0] / args.steps * 1e3 for r in per_rank]
+        launch_ms = [r[1] / args.steps for r in per_rank]
+        # the roofline is a per-GPU statement: the slowest rank's launch and its own shard
+        slow = max(range(world), key=lambda r: launch_ms[r])
+        bytes_per_launch = ALGORITHMIC_BYTES_PER_UPDATE * int(per_rank[slow][2])
+        achieved = bytes_per_launch / (launch_ms[slow] / 1e3) / 1e9
+        identity = build_identity(psim)
+        traffic = load_traffic(n, identity) if workload == "single" else \
+            {"traffic": None, "traffic_profiled_git_sha": None,
+             "traffic_build_match": "counters are collected for the single-attractor kernel"}
+        if workload == "single":
+            sharding = f"contiguous index ranges x{world}, no data-path collective"
+            kernel = "psim::update_kernel<colour 0, single attractor>"
+            what = "single attractor, SoA fp32, dt 0.016, damping 0.99, attractor (0,0,48) r 10 f 5"
+        else:
+            every = "every step" if args.lookahead == 1 or args.exchange == "native" else \
+                f"every {args.lookahead} steps ({args.lookahead} x 32 B per rank)"
+            sharding = (f"contiguous index ranges x{world}, all-gather of 32 B per rank {every} "
+                        f"({'psim_exchange_step: RCCL behind the C ABI' if args.exchange == 'native' else 'torch.distributed'})")
+            kernel = ("psim::update_kernel<colour 0, attractor list staged in LDS> "
+                      "(launch_ms here also holds the waits for the per-step all-gather)")
+            what = f"{world} moving attractors (one per rank, r 10 f 5) all-gathered over RCCL"
         out = {
             "metric": "particle-updates/sec @100M particles, 1/2/4/8 GPU; % HBM roofline",
             "value": total_updates / elapsed,
@@ -189,46 +365,52 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"{n} particles per GPU, single attractor, SoA fp32, dt 0.016, "
-                             "damping 0.99, attractor (0,0,48) r 10 f 5"
-                             if args.workload == "single" else
-                             f"{n} particles per GPU, {world} moving attractors all-gathered "
-                             "over RCCL every step"),
+                "workload": f"{config_name}: {n} particles per GPU x {world} GPU, {what}",
+                "baseline_config": args.config,
                 "particles_per_gpu": n,
-                "total_particles": world * n,
-                "sharding": f"contiguous index ranges x{world}, no data-path collective"
-                            if args.workload == "single" else
-                            (f"contiguous index ranges x{world}, all-gather of 32 B per rank per step"
-                             if args.lookahead == 1 else
-                             f"contiguous index ranges x{world}, all-gather of {args.lookahead} x 32 B "
-                             f"per rank every {args.lookahead} steps"),
+                "total_particles": total,
+                "sharding": sharding,
             },
+            "per_rank_ms_per_step": {"min": min(wall_ms), "max": max(wall_ms)},
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("psim::update_kernel<colour 0, single attractor>"
-                           if args.workload == "single" else
-                           "psim::update_kernel<colour 0, attractor list staged in LDS> "
-                           "(launch_ms here also holds the waits for the per-step all-gather)"),
+                "kernel": kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "launch_ms": launch_s * 1e3,
-                "traffic": load_traffic(n) if args.workload == "single" else None,
+                "launch_ms": launch_ms[slow],
+                "per_rank_launch_ms": {"min": min(launch_ms), "max": max(launch_ms)},
+                "per": "GPU (the slowest rank's launches over its own shard)",
+                **traffic,
+                **identity,
             },
         }
+        if check is not None:
+            out["exchange_check"] = check
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_seconds)
+            sample = args.cpu_sample
+            note = ""
+            if sample is None:
+                sample = n if host_memory_allows(n) else 20_000_000
+                if sample != n:
+                    note = f"; {n} records do not fit the free host memory"
+            out["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds)
+            out["cpu_baseline"]["sample"] += note
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    sim.close()
+    if runner is not None:
+        runner.close()
+    elif sim is not None:
+        sim.close()
     if distributed:
+        barrier()
         dist.destroy_process_group()
 
 

@@ -92,7 +92,8 @@ enum {
     PSIM_ERR_HIP       = 2,   /* a HIP runtime call failed */
     PSIM_ERR_NOMEM     = 3,   /* device or host allocation failed */
     PSIM_ERR_NO_DEVICE = 4,   /* no usable gfx950 device */
-    PSIM_ERR_IO        = 5    /* a checkpoint file could not be opened, read or written */
+    PSIM_ERR_IO        = 5,   /* a file could not be opened, read or written */
+    PSIM_ERR_COMM      = 6    /* RCCL could not be loaded, or a collective call failed */
 };
 
 /* `enum SphereGeneration` (src/simulation/mod.rs:15-19) plus the synthetic
@@ -463,6 +464,58 @@ int psim_group_upload_aos(psim_group *g, const psim_particle *src_host, uint64_t
 int psim_group_checksum(psim_group *g, uint64_t out[6]);
 int psim_group_checkpoint_write(psim_group *g, const char *path, uint64_t step);
 int psim_group_checkpoint_read(psim_group *g, const char *path, uint64_t *step_out);
+
+/* ---- one process per GPU: the attractor exchange ------------------------------ */
+
+/* The multi-attractor step of a set that is sharded over one process per GPU (each rank a
+ * psim_create_shard handle): every rank owns ONE attractor, a step all-gathers the ranks'
+ * 32-byte records with RCCL -- over xGMI between the GPUs of a node -- and applies all of
+ * them, rank 0's first, with psim_update_multi.  No counterpart in the reference, which has
+ * one attractor and one process (src/simulation/mod.rs:65, src/simulation/cpu.rs:58); with
+ * one rank a step equals psim_update with that rank's attractor.  The single-attractor
+ * configurations need none of this: their 48-byte SimParams is replicated by the hosts.
+ *
+ * The exchange is 32 bytes per rank, bound by latency, so it runs on a stream of its own
+ * into a ring of 16 receive lists and overlaps the previous steps' kernels; a step only
+ * enqueues work and returns (about 15 us of host time).  librccl.so.1 is loaded on the first call of this section
+ * (PSIM_RCCL_LIBRARY names another file), never by the rest of the library. */
+#define PSIM_EXCHANGE_ID_BYTES 128
+typedef struct psim_exchange psim_exchange;
+
+/* A fresh communicator id (RCCL's ncclUniqueId).  ONE rank makes it; the caller hands the
+ * same 128 bytes to every rank over whatever channel it has (MPI, a socket, a file). */
+int psim_exchange_unique_id(uint8_t id[PSIM_EXCHANGE_ID_BYTES]);
+
+/* That channel for callers that have none: rank 0 makes an id and publishes it as the file
+ * `path` (written under another name, then renamed, so it is never seen incomplete); every
+ * other rank waits up to timeout_ms for the file and reads it.  `path` must be fresh for
+ * every run (a file left by an earlier run would be taken for this run's) and visible to
+ * all ranks, e.g. under /dev/shm for the ranks of one node. */
+int psim_exchange_rendezvous_file(const char *path, int rank,
+                                  uint8_t id[PSIM_EXCHANGE_ID_BYTES], uint32_t timeout_ms);
+
+/* Joins the communicator `id` as `rank` of `world` (at most PSIM_MAX_ATTRACTORS) on the
+ * device of `h`; collective: returns once every rank has called it.  The handle stays the
+ * caller's and must outlive the exchange. */
+int psim_exchange_create(psim_exchange **out, psim_handle *h,
+                         const uint8_t id[PSIM_EXCHANGE_ID_BYTES], int rank, int world);
+void psim_exchange_destroy(psim_exchange *x);
+
+/* One step: this rank's attractor `mine` (host memory, copied before returning) joins the
+ * other ranks'; all `world` of them are applied to the handle's particles as
+ * psim_update_multi does (mouse_* of `params` ignored).  Collective and asynchronous. */
+int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
+                       const psim_attractor *mine);
+
+/* Waits for everything the exchange and its handle have enqueued. */
+int psim_exchange_sync(psim_exchange *x);
+
+/* The `world` records the most recent step applied, in rank order, into host memory (waits
+ * for that step): lets a caller check what the collective delivered. */
+int psim_exchange_last_list(psim_exchange *x, psim_attractor *out_host);
+
+int psim_exchange_world(const psim_exchange *x);
+int psim_exchange_rank(const psim_exchange *x);
 
 /* ---- errors --------------------------------------------------------------- */
 

@@ -182,6 +182,15 @@ ABI = {
     "psim_group_checksum": (c_int, [_P, POINTER(c_uint64)]),
     "psim_group_checkpoint_write": (c_int, [_P, c_char_p, c_uint64]),
     "psim_group_checkpoint_read": (c_int, [_P, c_char_p, POINTER(c_uint64)]),
+    "psim_exchange_unique_id": (c_int, [_P]),
+    "psim_exchange_rendezvous_file": (c_int, [c_char_p, c_int, _P, c_uint32]),
+    "psim_exchange_create": (c_int, [POINTER(_P), _P, _P, c_int, c_int]),
+    "psim_exchange_destroy": (None, [_P]),
+    "psim_exchange_step": (c_int, [_P, POINTER(SimParams), _P]),
+    "psim_exchange_sync": (c_int, [_P]),
+    "psim_exchange_last_list": (c_int, [_P, _P]),
+    "psim_exchange_world": (c_int, [_P]),
+    "psim_exchange_rank": (c_int, [_P]),
     "psim_set_stream": (c_int, [_P, _P]),
     "psim_get_stream": (_P, [_P]),
     "psim_device": (c_int, [_P]),
@@ -544,6 +553,81 @@ class HipParticleGroup:
         step = c_uint64(0)
         _check(self._lib.psim_group_checkpoint_read(self._g, os.fsencode(path), byref(step)))
         return int(step.value)
+
+
+EXCHANGE_ID_BYTES = 128
+
+
+def exchange_unique_id():
+    """A fresh communicator id (128 bytes) for HipAttractorExchange; ONE rank makes it and
+    the caller hands it to all ranks."""
+    buf = (ctypes.c_uint8 * EXCHANGE_ID_BYTES)()
+    _check(load_library().psim_exchange_unique_id(buf))
+    return bytes(buf)
+
+
+def exchange_rendezvous_file(path, rank, timeout_ms=60_000):
+    """The id through a file: rank 0 makes and publishes it at `path` (fresh per run), the
+    other ranks wait for it.  Returns the 128 bytes."""
+    buf = (ctypes.c_uint8 * EXCHANGE_ID_BYTES)()
+    _check(load_library().psim_exchange_rendezvous_file(os.fsencode(path), int(rank), buf,
+                                                        int(timeout_ms)))
+    return bytes(buf)
+
+
+class HipAttractorExchange:
+    """`psim_exchange_*`: the multi-attractor step of a set sharded over one process per GPU.
+    Every rank owns one attractor; step() all-gathers the ranks' records with RCCL on a stream
+    of its own (into a ring of receive lists, overlapping the previous steps' kernels) and applies them all
+    to the particles of `sim`.  No torch involved."""
+
+    def __init__(self, sim, unique_id, rank, world):
+        self._lib = load_library()
+        if len(unique_id) != EXCHANGE_ID_BYTES:
+            raise ValueError("the id is 128 bytes")
+        self._sim = sim                              # must outlive the exchange
+        ident = (ctypes.c_uint8 * EXCHANGE_ID_BYTES).from_buffer_copy(unique_id)
+        x = c_void_p()
+        _check(self._lib.psim_exchange_create(byref(x), sim.handle, ident, int(rank), int(world)))
+        self._x = x
+        self.rank, self.world = int(rank), int(world)
+
+    def step(self, params, mine):
+        arr = _as_attractors(mine).reshape(-1)[:1]
+        _check(self._lib.psim_exchange_step(self._x, byref(params), arr.ctypes.data_as(c_void_p)))
+
+    def step_at(self, params_ref, mine_address):
+        """step() for tight loops: `params_ref` = ctypes.byref(params) made once,
+        `mine_address` = the address of a 32-byte attractor record in host memory."""
+        rc = self._lib.psim_exchange_step(self._x, params_ref, mine_address)
+        if rc:
+            _check(rc)
+
+    def sync(self):
+        _check(self._lib.psim_exchange_sync(self._x))
+
+    def last_list(self):
+        """The records the most recent step applied, in rank order."""
+        out = np.zeros(self.world, dtype=ATTRACTOR_DTYPE)
+        _check(self._lib.psim_exchange_last_list(self._x, out.ctypes.data_as(c_void_p)))
+        return out
+
+    def close(self):
+        if self._x:
+            self._lib.psim_exchange_destroy(self._x)
+            self._x = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def update_soa(px, py, pz, vx, vy, vz, color, count, params, stream=0):

@@ -12,6 +12,7 @@ double-buffered receive array and overlaps the previous step's kernel.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import numpy as np
@@ -95,6 +96,50 @@ def gathered_to_records(gathered):
     return arr.view(ATTRACTOR_DTYPE).reshape(-1)
 
 
+class NativeMultiAttractorRunner:
+    """One rank of the sharded multi-attractor simulation through the library's own exchange
+    (`psim_exchange_*`: RCCL all-gather on a communication stream into a ring of receive
+    lists, then the multi-attractor kernel): the same steps as MultiAttractorRunner without torch in the data
+    path.  `unique_id` is the 128-byte communicator id every rank received from the one that
+    made it (HipParticleSimulation-side helpers: exchange_unique_id, exchange_rendezvous_file).
+    Attractor `rank` follows the closed-form path of attractor_at()."""
+
+    def __init__(self, particles_per_rank, rank, world, local_rank, params, unique_id,
+                 force=5.0, radius=10.0, first=None, total=None):
+        from . import HipAttractorExchange
+        self.rank, self.world, self.params = rank, world, params
+        self.force, self.radius = force, radius
+        # this rank's shard [first, first + particles_per_rank) of `total` (default: equal shards)
+        self.sim = HipParticleSimulation.new_shard(
+            particles_per_rank, rank * particles_per_rank if first is None else first,
+            world * particles_per_rank if total is None else total,
+            GEN_UNIFORM, device_id=local_rank)
+        self.exchange = HipAttractorExchange(self.sim, unique_id, rank, world)
+        self.t = 0
+        self._path = None          # own attractor records for steps [_path_first, +len)
+        self._path_first = 0
+        self._path_address = 0
+        self._params_ref = ctypes.byref(params)
+
+    def step(self):
+        # The host side of a step must stay well under the kernel's 40-odd microseconds: the
+        # records come from a table refilled 256 steps at a time and are handed over by address.
+        k = self.t - self._path_first
+        if self._path is None or not 0 <= k < len(self._path):
+            self._path_first, k = self.t, 0
+            self._path = attractor_table(self.t, 256, self.rank, self.force, self.radius)
+            self._path_address = self._path.ctypes.data
+        self.exchange.step_at(self._params_ref, self._path_address + k * ATTRACTOR_DTYPE.itemsize)
+        self.t += 1
+
+    def finish(self):
+        self.exchange.sync()
+
+    def close(self):
+        self.exchange.close()
+        self.sim.close()
+
+
 class MultiAttractorRunner:
     """One rank of the sharded multi-attractor simulation on a GPU.
 
@@ -116,7 +161,7 @@ class MultiAttractorRunner:
     """
 
     def __init__(self, particles_per_rank, rank, world, local_rank, params, group=None,
-                 force=5.0, radius=10.0, lookahead=1):
+                 force=5.0, radius=10.0, lookahead=1, first=None, total=None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist, self._group = torch, dist, group
@@ -125,7 +170,8 @@ class MultiAttractorRunner:
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend nccl)")
         self.sim = HipParticleSimulation.new_shard(
-            particles_per_rank, rank * particles_per_rank, world * particles_per_rank,
+            particles_per_rank, rank * particles_per_rank if first is None else first,
+            world * particles_per_rank if total is None else total,
             GEN_UNIFORM, device_id=local_rank)
         dev = torch.device("cuda", local_rank)
         self.comm = torch.cuda.Stream(device=dev)

@@ -57,8 +57,21 @@ def main():
         f.write("kernel,counter,launches,mean_value_KiB,bytes_per_launch_corrected\n")
         f.write(f"{kernel},FETCH_SIZE,{nf},{fetch_kib:.3f},{read_bytes:.0f}\n")
         f.write(f"{kernel},WRITE_SIZE,{nw},{write_kib:.3f},{write_bytes:.0f}\n")
+    # Which build the counters belong to: the hashes bench.py computed on the GPU box in the
+    # traced run, and the commit of the tree they were taken from (summarised right after).
+    import subprocess
+    try:
+        git_sha = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=ROOT, text=True).strip()
+        if subprocess.check_output(["git", "status", "--porcelain", "--", "particle-simulation-3d_amd",
+                                    "include"], cwd=ROOT, text=True).strip():
+            git_sha += "+uncommitted"
+    except (OSError, subprocess.CalledProcessError):
+        git_sha = None
     summary = {
         "tag": tag,
+        "git_sha": git_sha,
+        "library_sha256": bench["roofline"].get("library_sha256"),
+        "kernel_sources_sha256": bench["roofline"].get("kernel_sources_sha256"),
         "particles": n,
         "kernel": stats.get("Name", kernel),
         "launches_traced": int(stats.get("Calls", 0)),

@@ -93,8 +93,66 @@ def test_one_rank_under_the_launcher_uses_rccl():
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
 
 
-def test_multi_workload_line():
-    out = run_bench("--workload", "multi", "--no-cpu-baseline")
+@pytest.mark.parametrize("exchange", ["native", "torch"])
+def test_multi_workload_line(exchange):
+    out = run_bench("--workload", "multi", "--exchange", exchange, "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and "cpu_baseline" not in out
     assert "all-gather" in out["config"]["sharding"]
-    assert out["value"] > 0
+    assert ("psim_exchange_step" in out["config"]["sharding"]) == (exchange == "native")
+    assert out["value"] > 0 and out["roofline"]["traffic"] is None
+
+
+@pytest.mark.parametrize("config,per_gpu,workload", [(2, 10_000_000, "single"),
+                                                      (3, 100_000_000, "single"),
+                                                      (4, 125_000_000, "single"),
+                                                      (5, 6_250_000, "multi")])
+def test_baseline_config_presets(config, per_gpu, workload):
+    """--config N names the baseline's configuration N as written.  Run at the preset's own
+    size when that takes a moment (2, 5), at a reduced size otherwise; the preset sizes are
+    checked against the table either way."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(T.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.CONFIGS[config][1] == per_gpu and bench.CONFIGS[config][3] == workload
+    full_size = config in (2, 5)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+           "--config", str(config), "--no-cpu-baseline"]
+    if not full_size:
+        cmd += ["--particles", "3000000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert out["config"]["baseline_config"] == config
+    assert out["config"]["workload"].startswith(f"configs[{config - 1}]")
+    assert out["config"]["particles_per_gpu"] == (per_gpu if full_size else 3_000_000)
+    assert ("all-gather" in out["config"]["sharding"]) == (workload == "multi")
+    assert out["per_rank_ms_per_step"]["min"] <= out["per_rank_ms_per_step"]["max"]
+    assert out["roofline"]["per_rank_launch_ms"]["max"] == out["roofline"]["launch_ms"]
+    assert len(out["roofline"]["library_sha256"]) == 64
+
+
+def test_strong_scaling_rehearsal():
+    """--scaling strong: the total is fixed and divided over the ranks (uneven by one when
+    it does not divide).  Two ranks on one GPU over gloo, as in the rehearsal above."""
+    env = dict(os.environ, PSIM_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    total = 2_000_001
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29545", os.path.join(T.ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "2", "--scaling", "strong",
+                        "--particles", str(total)],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:1000]
+    out = json.loads(lines[0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2
+    assert out["config"]["total_particles"] == total and out["config"]["particles_per_gpu"] == 1_000_000
+    assert abs(out["value"] - total * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-6
+    assert "exchange_check" not in out               # a rehearsal cannot run RCCL
