@@ -390,6 +390,10 @@ void *psim_get_stream(const psim_handle *h);
 /* Device ordinal the handle lives on. */
 int psim_device(const psim_handle *h);
 
+/* HIP devices this process sees (0 when there is none): the ordinals a handle, a shard or
+ * the device_ids of a group may name. */
+int psim_device_count(void);
+
 /* ---- timing ---------------------------------------------------------------- */
 
 /* Device-side timer around work enqueued on the handle's stream.  The reference
@@ -416,6 +420,19 @@ typedef struct psim_launch_shape_info {
     uint32_t resident_per_cu;     /* workgroups a CU's 160 KiB of LDS then holds (0 = not capped) */
 } psim_launch_shape_info;
 int psim_launch_shape(uint32_t count, uint32_t n_attractors, psim_launch_shape_info *out);
+
+/* What the runtime says about that shape on the handle's device: how many workgroups of
+ * the update kernel psim_update (n_attractors 0 or 1) or psim_update_multi (more) would
+ * launch for the handle's particle count, with `color_mode`, one CU holds at once
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor with the LDS reservation).  The residency
+ * cap is worth a fifth of the update's bandwidth, so a caller -- or a test -- can check that
+ * a driver update or a part with another LDS size has not undone it: for a capped shape the
+ * result must equal psim_launch_shape's resident_per_cu.  lds_bytes_per_workgroup (optional)
+ * receives the LDS one workgroup takes: what the kernel declares plus the reservation.  (A
+ * kernel that declares more than the reservation asks for -- colour modes 1 / 2 with a list
+ * of 5 to 8 attractors: 10496 B against 10240 -- is held by its own LDS: 15 per CU, not 16.) */
+int psim_launch_occupancy(psim_handle *h, uint32_t n_attractors, uint32_t color_mode,
+                          uint32_t *workgroups_per_cu, uint32_t *lds_bytes_per_workgroup);
 
 /* ---- several GPUs from one process ---------------------------------------- */
 

@@ -130,6 +130,7 @@ assert ctypes.sizeof(CheckpointHeader) == 64
 _P = c_void_p
 ABI = {
     "psim_launch_shape": (c_int, [c_uint32, c_uint32, POINTER(LaunchShapeInfo)]),
+    "psim_launch_occupancy": (c_int, [_P, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
     "psim_create": (c_int, [POINTER(_P), c_uint32, c_int, c_int]),
     "psim_create_shard": (c_int, [POINTER(_P), c_uint32, c_uint64, c_uint64, c_int, c_int]),
     "psim_destroy": (None, [_P]),
@@ -194,6 +195,7 @@ ABI = {
     "psim_set_stream": (c_int, [_P, _P]),
     "psim_get_stream": (_P, [_P]),
     "psim_device": (c_int, [_P]),
+    "psim_device_count": (c_int, []),
     "psim_timer_start": (c_int, [_P]),
     "psim_timer_stop": (c_int, [_P, POINTER(c_float)]),
     "psim_last_error": (c_char_p, []),
@@ -463,6 +465,14 @@ class HipParticleSimulation:
         _check(self._lib.psim_timer_stop(self._h, byref(ms)))
         return float(ms.value)
 
+    def launch_occupancy(self, n_attractors=1, color_mode=0):
+        """(workgroups of this handle's update kernel one CU holds at once, asked of the
+        runtime; LDS bytes one workgroup takes)."""
+        out, lds = c_uint32(), c_uint32()
+        _check(self._lib.psim_launch_occupancy(self._h, n_attractors, color_mode, byref(out),
+                                               byref(lds)))
+        return int(out.value), int(lds.value)
+
     @property
     def handle(self):
         return self._h
@@ -709,6 +719,11 @@ def read_checkpoint_records(path, first=0, n=None):
         return np.empty(0, dtype=PARTICLE_DTYPE)
     return np.memmap(path, dtype=PARTICLE_DTYPE, mode="r",
                      offset=CHECKPOINT_HEADER_BYTES + first * PARTICLE_DTYPE.itemsize, shape=(n,))
+
+
+def device_count():
+    """HIP devices this process sees."""
+    return int(load_library().psim_device_count())
 
 
 def version():

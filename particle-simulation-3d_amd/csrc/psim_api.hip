@@ -1336,6 +1336,16 @@ PSIM_API void *psim_get_stream(const psim_handle *h) { return h ? h->stream : nu
 
 PSIM_API int psim_device(const psim_handle *h) { return h ? h->device : -1; }
 
+PSIM_API int psim_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return ndev < 0 ? 0 : ndev;
+}
+
 // ---- timing -------------------------------------------------------------------
 
 PSIM_API int psim_timer_start(psim_handle *h)
@@ -1374,6 +1384,26 @@ PSIM_API int psim_launch_shape(uint32_t count, uint32_t n_attractors, psim_launc
     out->reserve_lds = t.reserve_lds;
     out->reserve_lds_colour = t.reserve_lds_colour;
     out->resident_per_cu = t.reserve_lds ? 163840u / t.reserve_lds : 0u;
+    return PSIM_OK;
+}
+
+PSIM_API int psim_launch_occupancy(psim_handle *h, uint32_t n_attractors, uint32_t color_mode,
+                                   uint32_t *workgroups_per_cu, uint32_t *lds_bytes_per_workgroup)
+{
+    CHECK_HANDLE(h);
+    if (!workgroups_per_cu) return fail(PSIM_ERR_INVALID, "null output");
+    if (n_attractors > PSIM_MAX_ATTRACTORS)
+        return fail(PSIM_ERR_INVALID, "%u attractors exceed the maximum of %u", n_attractors,
+                    PSIM_MAX_ATTRACTORS);
+    // 0 attractors: psim_update without dragging; 1: psim_update; more: psim_update_multi
+    const int force = n_attractors == 0 ? 0 : (n_attractors == 1 ? 1 : 2);
+    int blocks = 0;
+    uint32_t lds = 0;
+    HIP_TRY(psim::update_occupancy(color_mode, force, n_attractors,
+                                   tuning_for(h->count, n_attractors ? n_attractors : 1, h->overrides),
+                                   &blocks, &lds));
+    *workgroups_per_cu = blocks < 0 ? 0u : (uint32_t)blocks;
+    if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = lds;
     return PSIM_OK;
 }
 

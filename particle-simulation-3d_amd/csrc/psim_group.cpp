@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "psim_checkpoint_file.h"
@@ -24,17 +26,58 @@ namespace {
 
 // For every shard that overlaps [first, first + n): call fn(shard, first_in_shard, count,
 // offset_in_request).
+// Calls fn(k) for k = 0 .. n-1 on up to 16 host threads (k, k + threads, ... on one thread),
+// so that the shards' synchronous entry points -- generators, record transfers, checksums,
+// checkpoint I/O -- run on all devices at once instead of device after device.  Returns the
+// status of the lowest k that failed, with its message as this thread's last error.
+template <typename Fn>
+int for_each_concurrently(size_t n, Fn fn)
+{
+    if (n == 0) return PSIM_OK;
+    if (n == 1) return fn((size_t)0);
+    const size_t threads = n < 16 ? n : 16;
+    std::vector<int> status(n, PSIM_OK);
+    std::vector<std::string> message(n);
+    const auto work = [&](size_t t) {
+        for (size_t k = t; k < n; k += threads) {
+            try {
+                status[k] = fn(k);
+                if (status[k] != PSIM_OK) message[k] = psim_last_error();   // thread-local text
+            } catch (...) {
+                status[k] = PSIM_ERR_NOMEM;
+            }
+        }
+    };
+    try {
+        std::vector<std::thread> pool;
+        pool.reserve(threads);
+        size_t started = 1;
+        try {
+            for (; started < threads; ++started) pool.emplace_back(work, started);
+        } catch (...) {                              // no more threads: do their share here
+            for (size_t t = started; t < threads; ++t) work(t);
+        }
+        work(0);
+        for (auto &th : pool) th.join();
+    } catch (...) {
+        return psim_fail(PSIM_ERR_NOMEM, "host allocation failed");
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (status[k] != PSIM_OK) return psim_fail(status[k], "%s", message[k].c_str());
+    return PSIM_OK;
+}
+
+// For every shard that overlaps [first, first + n): call fn(shard, first_in_shard, count,
+// offset_in_request), the shards at the same time.
 template <typename Fn>
 int for_overlapping_shards(psim_group *g, uint64_t first, uint64_t n, Fn fn)
 {
-    for (size_t k = 0; k < g->shards.size(); ++k) {
+    return for_each_concurrently(g->shards.size(), [&](size_t k) {
         const uint64_t lo = first > g->first[k] ? first : g->first[k];
         const uint64_t hi = first + n < g->first[k + 1] ? first + n : g->first[k + 1];
-        if (lo >= hi) continue;
-        const int rc = fn(g->shards[k], lo - g->first[k], hi - lo, lo - first);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
+        if (lo >= hi) return (int)PSIM_OK;
+        return fn(g->shards[k], lo - g->first[k], hi - lo, lo - first);
+    });
 }
 
 int check_group_range(const psim_group *g, uint64_t first, uint64_t n)
@@ -65,26 +108,31 @@ PSIM_API int psim_group_create(psim_group **out, uint64_t total_count, const int
     // k * total / n without overflowing 64 bits: total = q * n + r
     const uint64_t q = total_count / n_shards, r = total_count % n_shards;
     try {
-        g->shards.reserve(n_shards);
         g->first.reserve(n_shards + 1u);
     } catch (...) {
         delete g;
         return psim_fail(PSIM_ERR_NOMEM, "host allocation failed");
     }
     for (uint32_t k = 0; k <= n_shards; ++k) g->first.push_back(q * k + r * k / n_shards);
-    for (uint32_t k = 0; k < n_shards; ++k) {
-        psim_handle *h = nullptr;
+    try {
+        g->shards.assign(n_shards, nullptr);
+    } catch (...) {
+        delete g;
+        return psim_fail(PSIM_ERR_NOMEM, "host allocation failed");
+    }
+    // every shard allocates and generates on its own device, all devices at once
+    const int rc = for_each_concurrently(n_shards, [&](size_t k) {
         const uint32_t count = (uint32_t)(g->first[k + 1] - g->first[k]);
         // a set of one shard still is a shard of itself: global_count must be non-zero
-        const int rc = total_count == 0
-                           ? psim_create(&h, 0, generation_mode, device_ids[k])
-                           : psim_create_shard(&h, count, g->first[k], total_count,
-                                               generation_mode, device_ids[k]);
-        if (rc != PSIM_OK) {
-            psim_group_destroy(g);
-            return rc;
-        }
-        g->shards.push_back(h);
+        return total_count == 0
+                   ? psim_create(&g->shards[k], 0, generation_mode, device_ids[k])
+                   : psim_create_shard(&g->shards[k], count, g->first[k], total_count,
+                                       generation_mode, device_ids[k]);
+    });
+    if (rc != PSIM_OK) {
+        const std::string why = psim_last_error();   // destroying must not lose the reason
+        psim_group_destroy(g);
+        return psim_fail(rc, "%s", why.c_str());
     }
     *out = g;
     return PSIM_OK;
@@ -143,11 +191,9 @@ PSIM_API int psim_group_sync(psim_group *g)
 PSIM_API int psim_group_reset(psim_group *g, int generation_mode)
 {
     if (!g) return psim_fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_reset(h, generation_mode);
-        if (rc != PSIM_OK) return rc;
-    }
-    return PSIM_OK;
+    return for_each_concurrently(g->shards.size(), [&](size_t k) {
+        return psim_reset(g->shards[k], generation_mode);
+    });
 }
 
 PSIM_API uint64_t psim_group_particle_count(const psim_group *g) { return g ? g->total : 0; }
@@ -193,12 +239,18 @@ PSIM_API int psim_group_checksum(psim_group *g, uint64_t out[6])
     if (!g) return psim_fail(PSIM_ERR_INVALID, "null group");
     if (!out) return psim_fail(PSIM_ERR_INVALID, "null output");
     for (int c = 0; c < 6; ++c) out[c] = 0;
-    for (psim_handle *h : g->shards) {
-        uint64_t part[6];
-        const int rc = psim_checksum(h, part);
-        if (rc != PSIM_OK) return rc;
-        for (int c = 0; c < 6; ++c) out[c] += part[c];
+    std::vector<uint64_t> part;
+    try {
+        part.assign(6 * g->shards.size(), 0);
+    } catch (...) {
+        return psim_fail(PSIM_ERR_NOMEM, "host allocation failed");
     }
+    const int rc = for_each_concurrently(g->shards.size(), [&](size_t k) {
+        return psim_checksum(g->shards[k], &part[6 * k]);
+    });
+    if (rc != PSIM_OK) return rc;
+    for (size_t k = 0; k < g->shards.size(); ++k)
+        for (int c = 0; c < 6; ++c) out[c] += part[6 * k + c];
     return PSIM_OK;
 }
 
@@ -208,19 +260,27 @@ PSIM_API int psim_group_checkpoint_write(psim_group *g, const char *path, uint64
     if (!path) return psim_fail(PSIM_ERR_INVALID, "null path");
     int rc = psim_checkpoint_begin(path);        // no valid header while the records change
     if (rc != PSIM_OK) return rc;
-    for (psim_handle *h : g->shards) {
-        rc = psim_checkpoint_write(h, path, step);
-        if (rc != PSIM_OK) return rc;
-    }
+    rc = for_each_concurrently(g->shards.size(), [&](size_t k) {
+        return psim_checkpoint_write(g->shards[k], path, step);
+    });
+    if (rc != PSIM_OK) return rc;
     return psim_checkpoint_commit(g->shards[0], path, step);
 }
 
 PSIM_API int psim_group_checkpoint_read(psim_group *g, const char *path, uint64_t *step_out)
 {
     if (!g) return psim_fail(PSIM_ERR_INVALID, "null group");
-    for (psim_handle *h : g->shards) {
-        const int rc = psim_checkpoint_read(h, path, step_out);
-        if (rc != PSIM_OK) return rc;
+    if (!path) return psim_fail(PSIM_ERR_INVALID, "null path");
+    std::vector<uint64_t> steps;
+    try {
+        steps.assign(g->shards.size(), 0);
+    } catch (...) {
+        return psim_fail(PSIM_ERR_NOMEM, "host allocation failed");
     }
+    const int rc = for_each_concurrently(g->shards.size(), [&](size_t k) {
+        return psim_checkpoint_read(g->shards[k], path, &steps[k]);
+    });
+    if (rc != PSIM_OK) return rc;
+    if (step_out && !steps.empty()) *step_out = steps[0];
     return PSIM_OK;
 }

@@ -53,6 +53,12 @@ hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
                          const psim_attractor *attr_dev, const psim_attractor *attr_host,
                          uint32_t na, const LaunchTuning &t, hipStream_t stream);
 
+// Workgroups of that update (same picking of the kernel instantiation and of its dynamic LDS)
+// that one CU holds at once according to the runtime, and the LDS one of them takes (what the
+// kernel declares plus the reservation); needs a current device.
+hipError_t update_occupancy(uint32_t color_mode, int force, uint32_t na, const LaunchTuning &t,
+                            int *workgroups_per_cu, uint32_t *lds_bytes);
+
 // nsteps <= PSIM_BATCH_STEPS consecutive single-attractor steps in one pass over the state.
 hipError_t launch_update_batch(const SoaPtrs &s, uint32_t n, const psim_sim_params *params,
                                uint32_t nsteps, const LaunchTuning &t, hipStream_t stream);

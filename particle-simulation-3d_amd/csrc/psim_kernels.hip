@@ -754,11 +754,19 @@ static psim_attractor with_threshold(const psim_attractor &a)
     return q;
 }
 
+// Every instantiation of update_kernel has the same signature, so a launch is "pick the
+// instantiation and its dynamic LDS, then launch through the pointer"; the occupancy query
+// (update_occupancy) picks the same way.
+using UpdateKernel = void (*)(SoaPtrs, uint32_t, psim_sim_params, const psim_attractor *, uint32_t,
+                              KernargAttractors);
+
+struct UpdateLaunch {
+    UpdateKernel kernel;
+    uint32_t dynamic_lds;
+};
+
 template <int CM, int FORCE>
-static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
-                            const psim_attractor *attr_dev, uint32_t na,
-                            const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
-                            hipStream_t stream)
+static UpdateLaunch pick_nt(const LaunchTuning &t)
 {
     // t.reserve_lds bytes of dynamic LDS are requested but never touched: they only
     // limit how many workgroups a CU holds at once (see choose_tuning()).
@@ -776,31 +784,51 @@ static hipError_t launch_nt(const SoaPtrs &s, uint32_t n, const psim_sim_params 
     if ((FORCE == 2 || FORCE == 4) && want > 11776u) want = 11776u;
     const uint32_t extra = want > used ? want - used : 0;
     switch (t.access) {
-    case PSIM_ACCESS_STREAM:
-        hipLaunchKernelGGL((update_kernel<CM, FORCE, PSIM_ACCESS_STREAM>), dim3(grid),
-                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, p, attr_dev, na, ka);
-        break;
-    case PSIM_ACCESS_RESIDENT:
-        hipLaunchKernelGGL((update_kernel<CM, FORCE, PSIM_ACCESS_RESIDENT>), dim3(grid),
-                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, p, attr_dev, na, ka);
-        break;
-    default:
-        hipLaunchKernelGGL((update_kernel<CM, FORCE, PSIM_ACCESS_PLAIN>), dim3(grid),
-                           dim3(PSIM_UPDATE_BLOCK), extra, stream, s, n, p, attr_dev, na, ka);
+    case PSIM_ACCESS_STREAM: return {update_kernel<CM, FORCE, PSIM_ACCESS_STREAM>, extra};
+    case PSIM_ACCESS_RESIDENT: return {update_kernel<CM, FORCE, PSIM_ACCESS_RESIDENT>, extra};
+    default: return {update_kernel<CM, FORCE, PSIM_ACCESS_PLAIN>, extra};
     }
-    return hipGetLastError();
 }
 
 template <int FORCE>
-static hipError_t launch_cm(const SoaPtrs &s, uint32_t n, const psim_sim_params &p,
-                            const psim_attractor *attr_dev, uint32_t na,
-                            const KernargAttractors &ka, const LaunchTuning &t, uint32_t grid,
-                            hipStream_t stream)
+static UpdateLaunch pick_cm(uint32_t color_mode, const LaunchTuning &t)
 {
-    switch (p.color_mode) {
-    case 1: return launch_nt<1, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
-    case 2: return launch_nt<2, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
-    default: return launch_nt<0, FORCE>(s, n, p, attr_dev, na, ka, t, grid, stream);
+    switch (color_mode) {
+    case 1: return pick_nt<1, FORCE>(t);
+    case 2: return pick_nt<2, FORCE>(t);
+    default: return pick_nt<0, FORCE>(t);
+    }
+}
+
+// Experiments only: PSIM_QUEUE_FROM overrides the list length from which the queued form
+// is used (0 = never).
+static uint32_t queue_from()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("PSIM_QUEUE_FROM");
+        const int x = e && *e ? atoi(e) : 2;
+        return x <= 0 ? 0xFFFFFFFFu : (uint32_t)x;
+    }();
+    return v;
+}
+
+// force as launch_update() takes it (0 none, 1 SimParams, 2 device list, 3 host list).
+static UpdateLaunch pick_update(uint32_t color_mode, int force, uint32_t na, const LaunchTuning &t)
+{
+    // Lists of two attractors and more go through the queue of in-range pairs (100 M
+    // particles, r = 10, ms per step with / without: 2 attractors in device memory 0.759 /
+    // 0.811, 4: 0.751 / 0.858, 8: 0.768 / 1.00, 16: 0.899 / 1.96, 64: 2.40 / 7.59; lists that
+    // came in the kernel arguments: 2-4 attractors equal, 8: 0.761 / 0.947).
+    // A list in device memory is staged into LDS anyway and takes the queue from one
+    // attractor on.
+    const uint32_t from = queue_from();
+    if (force >= 2 && na >= 1 && from != 0xFFFFFFFFu && (force == 2 || na >= from))
+        return pick_cm<4>(color_mode, t);
+    switch (force) {
+    case 0: return pick_cm<0>(color_mode, t);
+    case 1: return pick_cm<1>(color_mode, t);
+    case 2: return pick_cm<2>(color_mode, t);
+    default: return pick_cm<3>(color_mode, t);
     }
 }
 
@@ -873,18 +901,6 @@ LaunchTuning choose_tuning(uint32_t n, uint32_t n_attractors)
     return t;
 }
 
-// Experiments only: PSIM_QUEUE_FROM overrides the list length from which the queued form
-// is used (0 = never).
-static uint32_t queue_from()
-{
-    static const uint32_t v = [] {
-        const char *e = getenv("PSIM_QUEUE_FROM");
-        const int x = e && *e ? atoi(e) : 2;
-        return x <= 0 ? 0xFFFFFFFFu : (uint32_t)x;
-    }();
-    return v;
-}
-
 hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &params, int force,
                          const psim_attractor *attr_dev, const psim_attractor *attr_host,
                          uint32_t na, const LaunchTuning &t, hipStream_t stream)
@@ -895,22 +911,25 @@ hipError_t launch_update(const SoaPtrs &s, uint32_t n, const psim_sim_params &pa
     memset(&ka, 0, sizeof(ka));
     if (force == 3)
         for (uint32_t a = 0; a < na; ++a) ka.a[a] = with_threshold(attr_host[a]);
-    const uint32_t grid = update_grid(n, t);
-    // Lists of two attractors and more go through the queue of in-range pairs (100 M
-    // particles, r = 10, ms per step with / without: 2 attractors in device memory 0.759 /
-    // 0.811, 4: 0.751 / 0.858, 8: 0.768 / 1.00, 16: 0.899 / 1.96, 64: 2.40 / 7.59; lists that
-    // came in the kernel arguments: 2-4 attractors equal, 8: 0.761 / 0.947).
-    // A list in device memory is staged into LDS anyway and takes the queue from one
-    // attractor on.
-    const uint32_t from = queue_from();
-    if (force >= 2 && na >= 1 && from != 0xFFFFFFFFu && (force == 2 || na >= from))
-        return launch_cm<4>(s, n, p, force == 2 ? attr_dev : nullptr, na, ka, t, grid, stream);
-    switch (force) {
-    case 0: return launch_cm<0>(s, n, p, nullptr, 0, ka, t, grid, stream);
-    case 1: return launch_cm<1>(s, n, p, nullptr, 0, ka, t, grid, stream);
-    case 2: return launch_cm<2>(s, n, p, attr_dev, na, ka, t, grid, stream);
-    default: return launch_cm<3>(s, n, p, nullptr, na, ka, t, grid, stream);
-    }
+    const UpdateLaunch l = pick_update(p.color_mode, force, na, t);
+    hipLaunchKernelGGL(l.kernel, dim3(update_grid(n, t)), dim3(PSIM_UPDATE_BLOCK), l.dynamic_lds,
+                       stream, s, n, p, force == 2 ? attr_dev : nullptr, force >= 2 ? na : 0u, ka);
+    return hipGetLastError();
+}
+
+// How many workgroups of the update psim_update / psim_update_multi would launch the
+// runtime says one CU holds at once, dynamic LDS reservation included.
+hipError_t update_occupancy(uint32_t color_mode, int force, uint32_t na, const LaunchTuning &t,
+                            int *workgroups_per_cu, uint32_t *lds_bytes)
+{
+    const UpdateLaunch l = pick_update(color_mode, force, na, t);
+    hipFuncAttributes attr;
+    const hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(l.kernel));
+    if (e != hipSuccess) return e;
+    *lds_bytes = (uint32_t)attr.sharedSizeBytes + l.dynamic_lds;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        workgroups_per_cu, reinterpret_cast<const void *>(l.kernel), PSIM_UPDATE_BLOCK,
+        l.dynamic_lds);
 }
 
 hipError_t launch_update_scalar(const SoaPtrs &s, uint32_t n, const psim_sim_params &params,

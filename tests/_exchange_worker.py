@@ -1,0 +1,161 @@
+"""Worker of tests/test_gpu_exchange.py: the attractor exchange behind the C ABI
+(psim_exchange_*) on the GPU, every case in this one process.  It runs apart from the test
+runner because the exchange maps RCCL (/opt/rocm/lib/librccl.so.1) and other tests of the
+suite import torch, which brings a ROCm stack of its own: a process that maps both aborts
+when it exits.  No torch anywhere in this file.
+
+usage: _exchange_worker.py <result.json> <scratch directory>"""
+import importlib
+import json
+import os
+import pathlib
+import sys
+import traceback
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import psim_testlib as T  # noqa: E402
+from psim_testlib import psim  # noqa: E402
+
+par = importlib.import_module("particle-simulation-3d_amd.parallel")
+
+
+def one_rank_steps_equal_the_oracle(steps):
+    n = 300_007
+    params = T.bench_params(gravity=0.5, is_mouse_dragging=0, color_mode=2)
+    runner = par.NativeMultiAttractorRunner(n, 0, 1, 0, params, psim.exchange_unique_id(),
+                                            force=60.0, radius=30.0)
+    try:
+        for _ in range(steps):
+            runner.step()
+        runner.finish()
+        got = runner.sim.download_aos()
+        last = runner.exchange.last_list()
+    finally:
+        runner.close()
+    want = T.oracle_gen_uniform_aos(0, n)
+    for t in range(steps):
+        want = T.oracle_update_aos(want, params, 1, par.attractors_at(t, 1, force=60.0, radius=30.0))
+    T.assert_particles_equal(got, want, f"{steps} exchanged steps")
+    assert last.tobytes() == par.attractors_at(steps - 1, 1, force=60.0, radius=30.0).tobytes()
+
+
+def case_one_rank_equals_the_single_attractor_update():
+    """With one rank the exchanged step is the reference's own step with that attractor."""
+    n = 100_003
+    mine = par.attractor_at(5, 0, force=40.0, radius=25.0)
+    params = T.bench_params(mouse_force=40.0, mouse_radius=25.0,
+                            mouse_position=tuple(float(v) for v in mine["position"][0]))
+    with psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM) as plain, \
+            psim.HipParticleSimulation.new_shard(n, 0, n, psim.GEN_UNIFORM) as sharded:
+        with psim.HipAttractorExchange(sharded, psim.exchange_unique_id(), 0, 1) as ex:
+            for _ in range(3):
+                plain.update(params)
+                ex.step(params, mine)
+            ex.sync()
+            assert sharded.download_aos().tobytes() == plain.download_aos().tobytes()
+
+
+def case_file_rendezvous_and_a_second_communicator(tmp_path):
+    """Rank 0 publishes the id as a file; a later reader gets the same bytes; two exchanges
+    (two communicators) can live in one process."""
+    path = tmp_path / "id"
+    ident = psim.exchange_rendezvous_file(path, 0)
+    assert len(ident) == 128 and path.read_bytes() == ident
+    assert psim.exchange_rendezvous_file(path, 1, timeout_ms=100) == ident
+    params = T.bench_params()
+    with psim.HipParticleSimulation.new_shard(10_000, 0, 10_000, psim.GEN_UNIFORM) as a, \
+            psim.HipParticleSimulation.new_shard(10_000, 0, 10_000, psim.GEN_UNIFORM) as b:
+        with psim.HipAttractorExchange(a, ident, 0, 1) as xa, \
+                psim.HipAttractorExchange(b, psim.exchange_unique_id(), 0, 1) as xb:
+            for t in range(4):
+                xa.step(params, par.attractor_at(t, 0))
+                xb.step(params, par.attractor_at(t, 0))
+            xa.sync()
+            xb.sync()
+            assert a.download_aos().tobytes() == b.download_aos().tobytes()
+
+
+def case_errors():
+    with psim.HipParticleSimulation.new_shard(1000, 0, 1000, psim.GEN_UNIFORM) as sim:
+        with psim.HipAttractorExchange(sim, psim.exchange_unique_id(), 0, 1) as ex:
+            with pytest.raises(psim.PsimError) as e:
+                ex.last_list()                           # no step yet
+            assert e.value.code == 1
+        with pytest.raises(ValueError):
+            psim.HipAttractorExchange(sim, b"short", 0, 1)
+
+
+def case_host_time_of_a_step_hides_behind_the_kernel():
+    """6.25 M particles (one GPU's share of the 50 M configuration): the exchanged step must
+    cost about what its kernel costs -- nothing in it waits on the host.  Informational
+    figures are printed; the bound asserted is loose (shared test machines)."""
+    n, steps = 6_250_000, 300
+    params = T.bench_params()
+    runner = par.NativeMultiAttractorRunner(n, 0, 1, 0, params, psim.exchange_unique_id())
+    try:
+        for _ in range(30):
+            runner.step()
+        runner.finish()
+        runner.sim.timer_start()
+        for _ in range(steps):
+            runner.step()
+        exchanged = runner.sim.timer_stop() / steps * 1e3
+        runner.finish()
+        table = par.attractors_at(0, 1)
+        for _ in range(30):
+            runner.sim.update_multi(params, table)
+        runner.sim.timer_start()
+        for _ in range(steps):
+            runner.sim.update_multi(params, table)
+        kernel = runner.sim.timer_stop() / steps * 1e3
+    finally:
+        runner.close()
+    print(f"exchanged step {exchanged:.1f} us, the same kernel from a host list {kernel:.1f} us")
+    assert exchanged < 1.3 * kernel + 8.0
+
+
+
+def case_one_rank_steps_equal_the_oracle_1():
+    one_rank_steps_equal_the_oracle(1)
+
+
+def case_one_rank_steps_equal_the_oracle_2():
+    one_rank_steps_equal_the_oracle(2)
+
+
+def case_one_rank_steps_equal_the_oracle_7():
+    one_rank_steps_equal_the_oracle(7)
+
+
+def case_one_rank_steps_equal_the_oracle_40():
+    one_rank_steps_equal_the_oracle(40)              # the ring of 16 lists goes round
+
+
+CASES = sorted(name for name in globals() if name.startswith("case_"))
+
+
+def main():
+    out_path, scratch = sys.argv[1], pathlib.Path(sys.argv[2])
+    results = {}
+    for name in CASES:
+        fn = globals()[name]
+        try:
+            if fn.__code__.co_argcount:
+                d = scratch / name
+                d.mkdir()
+                fn(d)
+            else:
+                fn()
+            results[name] = "ok"
+        except BaseException:                        # noqa: BLE001 -- reported, not swallowed
+            results[name] = traceback.format_exc()
+        print(name, "->", results[name][:200], flush=True)
+    with open(out_path, "w") as f:
+        json.dump(results, f)
+
+
+if __name__ == "__main__":
+    main()

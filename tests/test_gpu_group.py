@@ -103,3 +103,39 @@ def test_group_multi_attractor_step(k):
             g.update_multi(params(), attrs)
         got = g.download_aos()
     T.assert_particles_equal(got, T.oracle_update_aos(start, params(), 3, attrs), f"{k} attractors")
+
+
+def test_group_over_every_visible_device():
+    """One shard per visible GPU (and a second round of them, so that two shards share each
+    device): with one GPU this is the partition test again; on a larger machine the shards
+    really live on distinct devices, are created, reset, summed and transferred on all of
+    them at once, and must still equal one handle holding the whole set."""
+    ndev = psim.device_count()
+    assert ndev >= 1
+    devices = list(range(ndev)) * 2
+    total = 1_000_003
+    with Group(total, devices, psim.GEN_FILLED) as g, Sim.new(total, psim.GEN_FILLED) as one:
+        assert [g.shard(k).device() for k in range(len(devices))] == devices
+        assert g.download_aos().tobytes() == one.download_aos().tobytes()
+        lst = np.zeros(3, dtype=psim.ATTRACTOR_DTYPE)
+        lst["position"] = [(0, 0, 30), (20, -10, 0), (-30, 5, 5)]
+        lst["force"], lst["radius"], lst["active"] = 30.0, 25.0, 1
+        for step in range(3):
+            p = params(color_mode=step % 3)
+            g.update(p)
+            one.update(p)
+            g.update_multi(p, lst)
+            one.update_multi(p, lst)
+        g.sync()
+        assert g.checksum() == one.checksum()
+        assert g.download_aos().tobytes() == one.download_aos().tobytes()
+        g.reset(psim.GEN_UNIFORM)
+        one.reset(psim.GEN_UNIFORM)
+        assert g.checksum() == one.checksum()
+
+
+def test_group_reports_the_failing_shard():
+    """Errors of the concurrently created shards reach the caller with their text."""
+    with pytest.raises(psim.PsimError) as e:
+        Group(1000, [0, 9999], psim.GEN_UNIFORM)
+    assert e.value.code == 1 and "out of range" in str(e.value)

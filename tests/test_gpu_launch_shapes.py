@@ -77,3 +77,30 @@ def test_streaming_stores_at_wave_boundaries(knobs, n):
         sim.update(p)
         T.assert_particles_equal(sim.download_aos(), T.oracle_update_aos(start, p, 1),
                                  f"streaming stores, n = {n}")
+
+
+@pytest.mark.parametrize("n", [1_000_000, 4_200_000, 12_500_000, 16_000_000])
+def test_achieved_residency_equals_the_intended_one(n):
+    """The residency cap (untouched LDS reserved per single-wave workgroup) is worth a fifth
+    of the update's bandwidth at streaming sizes.  psim_launch_shape reports what the library
+    intends; here the runtime is asked what a CU really holds for the very kernel instantiation
+    and LDS reservation a launch would use -- so a runtime update or a part with another LDS
+    size cannot undo the cap unnoticed.  Sizes: fits the L2s / the Infinity Cache / the band
+    just above it (one GPU's share of 100 M over 8) / streaming."""
+    with Sim.new(n, psim.GEN_UNIFORM) as sim:
+        for na in (0, 1, 2, 4, 8, 16):
+            shape = psim.launch_shape(n, max(na, 1))
+            for colour in (0, 1, 2):
+                got, lds = sim.launch_occupancy(na, colour)
+                reserve = shape["reserve_lds_colour"] if colour else shape["reserve_lds"]
+                what = (f"{n} particles, {na} attractors, colour mode {colour}: reserve {reserve}, "
+                        f"LDS per workgroup {lds}, resident {got}")
+                if reserve:
+                    # the reservation is what a workgroup takes, unless the kernel's own
+                    # arrays are larger (colour tile + list + pair queue = 10496 B)
+                    assert lds == max(reserve, 10496 if colour and na >= 2 else 0), what
+                    assert got == 163840 // lds, what
+                    if colour == 0:
+                        assert got == shape["resident_per_cu"], what
+                else:
+                    assert shape["resident_per_cu"] == 0 and got >= 8, what
