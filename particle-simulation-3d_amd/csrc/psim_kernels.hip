@@ -1178,6 +1178,136 @@ __global__ void __launch_bounds__(BLOCK) import_aos_kernel(SoaPtrs s, uint32_t f
     }
 }
 
+// ---- the transposes with several particles per lane -------------------------------------
+//
+// Above, a lane owns one particle, so the SoA side moves 4 bytes per lane: 256 bytes per wave
+// instruction on each of the six state arrays.  Here a single-wave workgroup moves
+// P = 64 * PPL particles (PPL = 2 or 4) and a lane owns PPL consecutive ones, so that every
+// access of either side covers 512 bytes or 1 KiB of consecutive addresses, like the update
+// kernel's.  Positions, velocities and the two padding floats cross LDS as eight rows of
+// floats, comp[c][particle]; the row length is 4 (mod 64) floats, which makes both the
+// scattered 4-byte side (lane = quad of a record: banks 16 * field + particle) and the
+// 16-byte side (lane = PPL consecutive particles) free of bank conflicts.  The two colours
+// are 16-byte units on both sides and cross as quads, quad[field][particle].  Full tiles
+// only: the launcher hands the last n % P particles to the one-particle-per-lane kernels.
+template <int PPL> struct LaneVec;
+template <> struct LaneVec<2> { typedef f32x2 type; };
+template <> struct LaneVec<4> { typedef f32x4 type; };
+
+template <bool NT, int PPL>
+__global__ void __launch_bounds__(64) import_aos_wide_kernel(SoaPtrs s, uint32_t first,
+                                                             const f32x4 *aos)
+{
+    typedef typename LaneVec<PPL>::type vec;
+    constexpr int P = 64 * PPL, ROW = P + 4;
+    __shared__ __align__(16) float comp[8][ROW];
+    __shared__ f32x4 quad[2][P + 2];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * P;          // tile's first particle, in the request
+    const f32x4 *src = aos + 4 * base;
+    f32x4 v[4 * PPL];
+#pragma unroll
+    for (int k = 0; k < 4 * PPL; ++k) v[k] = ld<NT>(src + k * 64 + lane);
+#pragma unroll
+    for (int k = 0; k < 4 * PPL; ++k) {
+        const uint32_t q = k * 64 + lane, particle = q >> 2, field = q & 3u;
+        if (field < 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) comp[4 * field + c][particle] = v[k][c];
+        } else {
+            quad[field - 2][particle] = v[k];
+        }
+    }
+    wave_lds_sync();
+    const uint64_t p0 = (uint64_t)first + base;              // in the handle's arrays
+    const uint32_t g = lane * PPL;
+    float *const arr[6] = {s.px, s.py, s.pz, s.vx, s.vy, s.vz};
+    constexpr int row_of[6] = {0, 1, 2, 4, 5, 6};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const vec x = *reinterpret_cast<const vec *>(&comp[row_of[a]][g]);
+        if constexpr (NT) st_stream(reinterpret_cast<vec *>(arr[a]), p0 / PPL, p0 / PPL + 64, lane, x);
+        else reinterpret_cast<vec *>(arr[a])[p0 / PPL + lane] = x;
+    }
+    // {padding1, padding2} pairs, two particles per 16 bytes
+#pragma unroll
+    for (int m = 0; m < PPL / 2; ++m) {
+        const uint32_t u = m * 64 + lane;                     // 16-byte unit = particles 2u, 2u + 1
+        const f32x2 a = *reinterpret_cast<const f32x2 *>(&comp[3][2 * u]);
+        const f32x2 b = *reinterpret_cast<const f32x2 *>(&comp[7][2 * u]);
+        const f32x4 pad = {a[0], b[0], a[1], b[1]};
+        f32x4 *dst = reinterpret_cast<f32x4 *>(s.padding);
+        if constexpr (NT) st_stream(dst, p0 / 2 + 64u * m, p0 / 2 + 64u * m + 64, lane, pad);
+        else dst[p0 / 2 + u] = pad;
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        f32x4 *col = reinterpret_cast<f32x4 *>(s.color), *ini = reinterpret_cast<f32x4 *>(s.initial_color);
+        if constexpr (NT) {
+            st_stream(col, p0 + 64u * k, p0 + 64u * k + 64, lane, quad[0][k * 64 + lane]);
+            st_stream(ini, p0 + 64u * k, p0 + 64u * k + 64, lane, quad[1][k * 64 + lane]);
+        } else {
+            col[p0 + k * 64 + lane] = quad[0][k * 64 + lane];
+            ini[p0 + k * 64 + lane] = quad[1][k * 64 + lane];
+        }
+    }
+}
+
+template <bool NT, int PPL>
+__global__ void __launch_bounds__(64) export_aos_wide_kernel(SoaPtrs s, uint32_t first, f32x4 *aos)
+{
+    typedef typename LaneVec<PPL>::type vec;
+    constexpr int P = 64 * PPL, ROW = P + 4;
+    __shared__ __align__(16) float comp[8][ROW];
+    __shared__ f32x4 quad[2][P + 4];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * P;
+    const uint64_t p0 = (uint64_t)first + base;
+    const uint32_t g = lane * PPL;
+    const float *const arr[6] = {s.px, s.py, s.pz, s.vx, s.vy, s.vz};
+    constexpr int row_of[6] = {0, 1, 2, 4, 5, 6};
+    vec x[6];
+    f32x4 pad[PPL / 2], col[PPL], ini[PPL];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) x[a] = ld<NT>(reinterpret_cast<const vec *>(arr[a]) + p0 / PPL + lane);
+#pragma unroll
+    for (int m = 0; m < PPL / 2; ++m)
+        pad[m] = ld<NT>(reinterpret_cast<const f32x4 *>(s.padding) + p0 / 2 + m * 64 + lane);
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        col[k] = ld<NT>(reinterpret_cast<const f32x4 *>(s.color) + p0 + k * 64 + lane);
+        ini[k] = ld<NT>(reinterpret_cast<const f32x4 *>(s.initial_color) + p0 + k * 64 + lane);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) *reinterpret_cast<vec *>(&comp[row_of[a]][g]) = x[a];
+#pragma unroll
+    for (int m = 0; m < PPL / 2; ++m) {
+        const uint32_t u = m * 64 + lane;
+        *reinterpret_cast<f32x2 *>(&comp[3][2 * u]) = f32x2{pad[m][0], pad[m][2]};
+        *reinterpret_cast<f32x2 *>(&comp[7][2 * u]) = f32x2{pad[m][1], pad[m][3]};
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) {
+        quad[0][k * 64 + lane] = col[k];
+        quad[1][k * 64 + lane] = ini[k];
+    }
+    wave_lds_sync();
+    f32x4 *dst = aos + 4 * base;
+#pragma unroll
+    for (int k = 0; k < 4 * PPL; ++k) {
+        const uint32_t q = k * 64 + lane, particle = q >> 2, field = q & 3u;
+        f32x4 v;
+        if (field < 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = comp[4 * field + c][particle];
+        } else {
+            v = quad[field - 2][particle];
+        }
+        if constexpr (NT) st_stream(dst, (uint64_t)k * 64, (uint64_t)k * 64 + 64, lane, v);
+        else dst[q] = v;
+    }
+}
+
 // Launch shape of the transposes, measured at 100 M particles (GB/s of the 128 B per
 // particle moved): plain, 32 waves per CU 5.34 k (export) / 5.36 k (import); with streaming
 // accesses and, through an LDS reservation, fewer resident waves per CU:
@@ -1202,19 +1332,19 @@ static int aos_env(const char *name)
 
 static bool aos_streaming(uint32_t n)
 {
-    static const int v = aos_env("PSIM_AOS_STREAM");
+    const int v = aos_env("PSIM_AOS_STREAM");          // read per launch: tests switch it
     return v >= 0 ? v != 0 : (uint64_t)n * 128u > 288000000ull;
 }
 
 static uint32_t aos_reserve(uint32_t automatic)
 {
-    static const int v = aos_env("PSIM_AOS_RESERVE");
+    const int v = aos_env("PSIM_AOS_RESERVE");          // read per launch: tests switch it
     return v >= 0 ? (uint32_t)v : automatic;
 }
 
 static bool aos_single_wave(bool automatic)
 {
-    static const int v = aos_env("PSIM_AOS_BLOCK");
+    const int v = aos_env("PSIM_AOS_BLOCK");          // read per launch: tests switch it
     return v == 64 ? true : (v == (int)PSIM_BLOCK ? false : automatic);
 }
 
@@ -1242,10 +1372,54 @@ static void launch_transpose(const SoaPtrs &s, uint32_t first, uint32_t n,
     }
 }
 
+// Experiments: PSIM_AOS_PPL = 1 (one particle per lane, the kernels above), 2 or 4.
+static int aos_ppl(int automatic)
+{
+    const int v = aos_env("PSIM_AOS_PPL");          // read per launch: tests switch it
+    return v == 1 || v == 2 || v == 4 ? v : automatic;
+}
+
+// The wide kernels over the full tiles of [first, first + n); returns how many particles they
+// covered (0 when they do not apply: the SoA side must be 16-byte aligned at `first`).
+template <bool IMPORT, typename Pointer>
+static uint32_t launch_wide(const SoaPtrs &s, uint32_t first, uint32_t n, Pointer aos, bool streaming,
+                            int ppl, uint32_t reserve, hipStream_t stream)
+{
+    if (ppl == 1 || (first & 3u) != 0) return 0;
+    const uint32_t tile = 64u * (uint32_t)ppl, tiles = n / tile;
+    if (tiles == 0) return 0;
+    const dim3 grid(tiles), block(64);
+    const uint32_t lds = aos_reserve(reserve);
+#define PSIM_WIDE(NT, PPL)                                                                      \
+    do {                                                                                        \
+        if constexpr (IMPORT)                                                                   \
+            hipLaunchKernelGGL((import_aos_wide_kernel<NT, PPL>), grid, block, lds, stream, s, first, aos); \
+        else                                                                                    \
+            hipLaunchKernelGGL((export_aos_wide_kernel<NT, PPL>), grid, block, lds, stream, s, first, aos); \
+    } while (0)
+    if (streaming) {
+        if (ppl == 4) PSIM_WIDE(true, 4); else PSIM_WIDE(true, 2);
+    } else {
+        if (ppl == 4) PSIM_WIDE(false, 4); else PSIM_WIDE(false, 2);
+    }
+#undef PSIM_WIDE
+    return tiles * tile;
+}
+
 hipError_t launch_export_aos(const SoaPtrs &s, uint32_t first, uint32_t n, psim_particle *aos,
                              hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+    {
+        const bool streaming = aos_streaming(n) && (reinterpret_cast<uintptr_t>(aos) & 127u) == 0 &&
+                               (first & 31u) == 0;
+        const uint32_t done = launch_wide<false>(s, first, n, reinterpret_cast<f32x4 *>(aos), streaming,
+                                                 aos_ppl(1), 0, stream);
+        if (done) {
+            first += done, n -= done, aos += done;
+            if (n == 0) return hipGetLastError();
+        }
+    }
     f32x4 *dst = reinterpret_cast<f32x4 *>(aos);
     // nt sc1 stores write partial 128-byte lines through to memory, which is slow: the
     // streaming form needs a line-aligned destination.
@@ -1260,6 +1434,21 @@ hipError_t launch_import_aos(const SoaPtrs &s, uint32_t first, uint32_t n,
                              const psim_particle *aos, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+    {
+        const bool streaming = aos_streaming(n) && (first & 31u) == 0 &&
+                               (reinterpret_cast<uintptr_t>(s.px) & 127u) == 0;
+        // Streaming import: two particles per lane and 5 resident waves per CU (24320 B on top
+        // of the kernel's 8384 B): 6.60 k GB/s at 100 M particles against 6.27 k for one
+        // particle per lane, 6.43 against 6.26 k at 20 M, 6.25 against 5.95 k at 4 M (6 waves
+        // 6.2-6.4 k, 4 waves equal, 3 waves 6.1 k; four particles per lane 6.3 k at best).  The
+        // export gains nothing from wider lanes (6.35-6.46 k against 6.60-6.63 k).
+        const uint32_t done = launch_wide<true>(s, first, n, reinterpret_cast<const f32x4 *>(aos),
+                                                streaming, aos_ppl(streaming ? 2 : 1), 24320, stream);
+        if (done) {
+            first += done, n -= done, aos += done;
+            if (n == 0) return hipGetLastError();
+        }
+    }
     const f32x4 *src = reinterpret_cast<const f32x4 *>(aos);
     // The SoA side stores 4 bytes per lane from particle `first` on: line-aligned only when
     // `first` is a multiple of 32 particles (the arrays themselves start 4 KiB-aligned).

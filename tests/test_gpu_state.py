@@ -141,6 +141,48 @@ def test_aos_round_trip_keeps_all_64_bytes(n):
         T.assert_same_f32(soa, T.aos_to_soa(p), "soa view of uploaded data")
 
 
+@pytest.mark.parametrize("stream", ["0", "1"])
+@pytest.mark.parametrize("ppl", ["1", "2", "4"])
+def test_transposes_with_several_particles_per_lane(ppl, stream):
+    """The AoS transposes exist with 1, 2 and 4 particles per lane, plain and streaming; the
+    library picks by size (PSIM_AOS_PPL / PSIM_AOS_STREAM force a form, read per launch).  Every
+    form must move all 64 bytes of every record, whole tiles, ragged tails and ranges that
+    start inside a tile or off a 4-particle boundary alike."""
+    import os
+    saved = {k: os.environ.get(k) for k in ("PSIM_AOS_PPL", "PSIM_AOS_STREAM")}
+    os.environ["PSIM_AOS_PPL"], os.environ["PSIM_AOS_STREAM"] = ppl, stream
+    try:
+        n = 70_001                                       # 273 tiles of 256 and a tail of 113
+        p = random_particles(n, 3)
+        with Sim.new(n, psim.GEN_UNIFORM) as sim:
+            view = sim.get_particle_buffer()
+            sim.upload_aos(p)
+            assert sim.download_aos().tobytes() == p.tobytes()
+            for first, m in ((0, 256), (4, 1000), (128, 512), (7, 300), (32, n - 32), (n - 5, 5),
+                             (1024, 64), (64, 63)):
+                part = random_particles(m, first + m)
+                sim.upload_aos(part, first=first)
+                p[first:first + m] = part
+                assert sim.download_aos(first, m).tobytes() == part.tobytes(), (first, m)
+            assert sim.download_aos().tobytes() == p.tobytes()
+            T.assert_same_f32(sim.download_soa(), T.aos_to_soa(p), "SoA side")
+            # device to device, into memory of another handle at an unaligned record offset
+            with Sim.new(2 * n, psim.GEN_UNIFORM) as other:
+                buf = other.get_particle_buffer().color + 64 * 3
+                sim.export_aos_device(buf, first=8, n=n - 8)
+                sim.sync()
+                sim.reset(psim.GEN_UNIFORM)
+                sim.import_aos_device(buf, first=8, n=n - 8)
+                assert sim.download_aos(8, n - 8).tobytes() == p[8:].tobytes()
+            assert view.count == n
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_soa_upload_download():
     n = 5000
     soa = np.random.default_rng(3).uniform(-9, 9, size=(6, n)).astype(np.float32)
