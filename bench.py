@@ -161,6 +161,42 @@ def load_traffic(particles, identity):
     return info
 
 
+EXCHANGE_CHECK_SECONDS = 120.0
+
+
+class Watchdog:
+    """Gives up on the code it guards after `seconds`, or when the launcher sends SIGTERM
+    (a sibling rank died): calls `give_up(reason)` on a thread of its own -- the main thread may
+    be blocked inside a collective that will never finish -- and ends the process."""
+
+    def __init__(self, seconds, give_up):
+        import select
+        import signal
+        import threading
+        self._signal = signal
+        self._sig_r, sig_w = os.pipe()
+        os.set_blocking(sig_w, False)
+        self._stop_r, self._stop_w = os.pipe()
+        self._old_fd = signal.set_wakeup_fd(sig_w, warn_on_full_buffer=False)
+        self._old_handler = signal.signal(signal.SIGTERM, lambda *a: None)
+
+        def watch():
+            ready, _, _ = select.select([self._sig_r, self._stop_r], [], [], seconds)
+            if self._stop_r in ready:
+                return
+            give_up("terminated by the launcher" if ready else f"no result after {seconds:.0f} s")
+            os._exit(0)
+
+        self._thread = threading.Thread(target=watch, daemon=True)
+        self._thread.start()
+
+    def cancel(self):
+        os.write(self._stop_w, b"x")
+        self._thread.join()
+        self._signal.signal(self._signal.SIGTERM, self._old_handler)
+        self._signal.set_wakeup_fd(self._old_fd)
+
+
 def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, steps=200, warmup=20):
     """The config-5 step (6.25 M particles per rank, one moving attractor per rank, RCCL
     all-gather every step through psim_exchange_*) over all ranks, untimed by the headline:
@@ -326,12 +362,7 @@ def main():
         per_rank = [[float(v) for v in r.tolist()] for r in everyone]
     barrier()
 
-    check = None
-    if world > 1 and workload == "single" and not rehearsal and not args.no_exchange_check:
-        sim.close()
-        sim = None
-        check = exchange_check(psim, par, torch, dist, rank, world, local_rank, params)
-
+    out = None
     if rank == 0:
         total_updates = total * args.steps
         wall_ms = [r[0] / args.steps * 1e3 for r in per_rank]
@@ -392,8 +423,6 @@ def main():
                 **identity,
             },
         }
-        if check is not None:
-            out["exchange_check"] = check
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample
             note = ""
@@ -403,7 +432,29 @@ def main():
                     note = f"; {n} records do not fit the free host memory"
             out["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds)
             out["cpu_baseline"]["sample"] += note
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    def emit(extra=None):
+        if rank == 0:
+            line = dict(out, exchange_check=extra) if extra is not None else out
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    if world > 1 and workload == "single" and not rehearsal and not args.no_exchange_check:
+        # The headline numbers are final at this point.  Whatever happens to the extra run --
+        # an error, a hang, a rank killed by the launcher -- the line still goes out.
+        sim.close()
+        sim = None
+        guard = Watchdog(EXCHANGE_CHECK_SECONDS,
+                         lambda why: emit({"error": f"exchange check abandoned: {why}"}))
+        try:
+            check = exchange_check(psim, par, torch, dist, rank, world, local_rank, params)
+        except Exception as e:                       # noqa: BLE001 -- reported in the line
+            check = {"error": f"{type(e).__name__}: {e}"}
+        guard.cancel()
+        emit(check)
+        if "error" in check:                         # the other ranks may be stuck in a collective:
+            os._exit(0)                              # no barrier, no tidy shutdown
+    else:
+        emit()
 
     if runner is not None:
         runner.close()
