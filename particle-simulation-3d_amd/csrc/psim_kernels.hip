@@ -139,6 +139,79 @@ __device__ __forceinline__ void attract(float &vx, float &vy, float &vz, float p
         attract_in_range(vx, vy, vz, dx, dy, dz, d2, aforce, two_r, dt);
 }
 
+// The single attractor of SimParams applied to a lane's four particles, for the kernels that
+// are bound by instruction issue (the fused batches).  The in-range test is cheap, the force
+// law behind it (attract_in_range: a correctly rounded square root and two divisions) costs
+// about as much as everything else in a step, and a wave runs it once per particle SLOT in
+// which any of its 64 lanes has a hit.  With r = 10 in the 100-unit cube 1.9 % of the
+// particles are in range: 2.8 of the 4 slots have a hit somewhere in the wave, although hardly
+// any lane has two.  So, when it pays, every lane first takes the FIRST of its particles that
+// is in range through one common run of the force law (selecting its inputs and scattering
+// its result costs about one more run), and what is left -- lanes with a second hit -- goes
+// slot by slot.  Whether it pays is decided per wave and step from wave-wide ballots: the
+// common run replaces (slots with a hit) - (slots still needed afterwards) slot runs and is
+// taken when that is 2 or more.  Small radii (at most one slot with a hit) and large ones
+// (every lane in range everywhere) therefore take the slot runs alone.  16 fused steps at 100 M
+// particles, ms with / without: r = 5 1.26 / 1.26, r = 10 1.66 / 2.00, r = 15 2.13 / 2.45, r = 20
+// and up equal.  Each particle gets exactly the operations of attract() either way.
+// PSIM_FIRST_HIT = 0 builds the kernels without it.
+#ifndef PSIM_FIRST_HIT
+#define PSIM_FIRST_HIT 1
+#endif
+#ifndef PSIM_FIRST_HIT_SINGLE       /* the same in the one-step kernel, which is HBM-bound */
+#define PSIM_FIRST_HIT_SINGLE 0
+#endif
+__device__ __forceinline__ void attract4_first_hits(float (&vx)[4], float (&vy)[4], float (&vz)[4],
+                                                    const float (&px)[4], const float (&py)[4],
+                                                    const float (&pz)[4], float ax, float ay,
+                                                    float az, float aforce, float two_r, float thr,
+                                                    float dt)
+{
+    float dx[4], dy[4], dz[4], d2[4];
+    bool take[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dx[j] = ax - px[j], dy[j] = ay - py[j], dz[j] = az - pz[j];      // cpu.rs:76
+        d2[j] = (dx[j] * dx[j] + dy[j] * dy[j]) + dz[j] * dz[j];
+        take[j] = d2[j] < thr;                                           // cpu.rs:79
+    }
+    // wave-uniform: slots with a hit, and slots that still have one once every lane's first
+    // hit is dealt with
+    const bool second1 = take[1] && take[0], second2 = take[2] && (take[0] || take[1]),
+               second3 = take[3] && (take[0] || take[1] || take[2]);
+    const int slots = (__builtin_amdgcn_ballot_w64(take[0]) != 0) + (__builtin_amdgcn_ballot_w64(take[1]) != 0) +
+                      (__builtin_amdgcn_ballot_w64(take[2]) != 0) + (__builtin_amdgcn_ballot_w64(take[3]) != 0);
+    const int left = (__builtin_amdgcn_ballot_w64(second1) != 0) + (__builtin_amdgcn_ballot_w64(second2) != 0) +
+                     (__builtin_amdgcn_ballot_w64(second3) != 0);
+    if (slots - left >= 2) {
+        // one-hot: the lane's first particle in range
+        const bool s0 = take[0], s1 = take[1] && !take[0], s2 = take[2] && !take[0] && !take[1],
+                   s3 = take[3] && !take[0] && !take[1] && !take[2];
+        if (s0 || s1 || s2 || s3) {
+            // Values, not array elements, go into the selections: `c ? v[0] : v[1]` on array
+            // elements is an lvalue -- a selected ADDRESS -- and would put the arrays into
+            // scratch memory (measured: 3.3 times slower).
+            const auto pick = [&](const float (&v)[4]) {
+                const float e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+                return s0 ? e0 : (s1 ? e1 : (s2 ? e2 : e3));
+            };
+            const float sx = pick(dx), sy = pick(dy), sz = pick(dz), sd = pick(d2);
+            float ux = pick(vx), uy = pick(vy), uz = pick(vz);
+            attract_in_range(ux, uy, uz, sx, sy, sz, sd, aforce, two_r, dt);
+            const auto put = [&](float (&v)[4], float u) {
+                const float e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+                v[0] = s0 ? u : e0; v[1] = s1 ? u : e1; v[2] = s2 ? u : e2; v[3] = s3 ? u : e3;
+            };
+            put(vx, ux); put(vy, uy); put(vz, uz);
+        }
+        take[0] = false, take[1] = second1, take[2] = second2, take[3] = second3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (take[j])
+            attract_in_range(vx[j], vy[j], vz[j], dx[j], dy[j], dz[j], d2[j], aforce, two_r, dt);
+}
+
 template <int N>
 __device__ __forceinline__ void apply_gravity(float (&vy)[N], const psim_sim_params &p)
 {
@@ -359,7 +432,11 @@ __device__ __forceinline__ void step(float (&px)[N], float (&py)[N], float (&pz)
     apply_gravity<N>(vy, p);
     // The in-range threshold of each attractor rides in a padding word of the kernel's own
     // copy of the record (SimParams::_padding2, psim_attractor::_pad[0]); see with_threshold().
-    if constexpr (FORCE == 1) {
+    if constexpr ((FORCE == 5 || (FORCE == 1 && PSIM_FIRST_HIT_SINGLE)) && N == 4) {   // first hits at once
+        attract4_first_hits(vx, vy, vz, px, py, pz, p.mouse_position[0], p.mouse_position[1],
+                        p.mouse_position[2], p.mouse_force, p.mouse_radius * 2.0f,
+                        __uint_as_float(p._padding2), dt);
+    } else if constexpr (FORCE == 1 || FORCE == 5) {
         const float two_r = p.mouse_radius * 2.0f;
         const float thr = __uint_as_float(p._padding2);
 #pragma unroll
@@ -632,7 +709,7 @@ __device__ __forceinline__ void step_batch(float (&a)[N], float (&b)[N], float (
 {
     for (uint32_t k = 0; k < nsteps; ++k) {
         const psim_sim_params &p = bp.p[k];
-        if (p.is_mouse_dragging > 0) step<1, N>(a, b, c, d, e, f, p, nullptr, 0);
+        if (p.is_mouse_dragging > 0) step<PSIM_FIRST_HIT ? 5 : 1, N>(a, b, c, d, e, f, p, nullptr, 0);
         else step<0, N>(a, b, c, d, e, f, p, nullptr, 0);
         if ((int)k == colour_step) {
 #pragma unroll

@@ -22,12 +22,13 @@ def main():
     ap.add_argument("--op", choices=OPS, required=True)
     ap.add_argument("--particles", type=int, default=100_000_000)
     ap.add_argument("--launches", type=int, default=3)
+    ap.add_argument("--radius", type=float, default=10.0)
     args = ap.parse_args()
     n = args.particles
     sim = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
 
     def P(**kw):
-        base = dict(is_mouse_dragging=1, mouse_position=(0.0, 0.0, 48.0))
+        base = dict(is_mouse_dragging=1, mouse_position=(0.0, 0.0, 48.0), mouse_radius=args.radius)
         base.update(kw)
         return psim.SimParams(**base)
 
@@ -43,7 +44,7 @@ def main():
         rng = np.random.default_rng(8)
         a = np.zeros(k, dtype=psim.ATTRACTOR_DTYPE)
         a["position"] = rng.uniform(-40, 40, size=(k, 3)).astype(np.float32)
-        a["force"], a["radius"], a["active"] = 5.0, 10.0, 1
+        a["force"], a["radius"], a["active"] = 5.0, args.radius, 1
         fn, kernel = (lambda: sim.update_multi(P(), a)), "update_kernel<0, 4, 2>"
     for _ in range(args.launches):
         fn()
