@@ -54,11 +54,11 @@ def main():
          lambda: sim.update(P(mouse_radius=50.0, color_mode=2))),
         ("update_kernel<0, 4, 2>", "update, 8 attractors r=10 through the pair queue", 48 * n,
          lambda: sim.update_multi_device(P(), attr_buf, 8)),
-        ("update_batch_kernel<2>", "16 fused steps", 48 * n,
+        ("update_batch_kernel<2>", "16 fused steps [bound by instruction issue]", 48 * n,
          lambda: sim.update_batch(batch)),
         ("export_aos_kernel<true, 256>", "SoA -> 64-byte records", 128 * n,
          lambda: sim.export_aos_device(aos_buf)),
-        ("import_aos_kernel<true, 64>", "64-byte records -> SoA", 128 * n,
+        ("import_aos_wide_kernel<true, 2>", "64-byte records -> SoA (two particles per lane)", 128 * n,
          lambda: sim.import_aos_device(aos_buf)),
         ("gen_uniform_kernel<true>", "synthetic state generator", 64 * n,
          lambda: sim.reset(psim.GEN_UNIFORM)),
@@ -70,7 +70,9 @@ def main():
             fn()
         sim.sync()
     json.dump({"particles": n, "launches": args.launches,
-               "kernels": [{"name": k, "what": w, "algorithmic_bytes": b} for k, w, b, _ in ops]},
+               "kernels": [{"name": k, "what": w, "algorithmic_bytes": b,
+                            "bound": "valu" if "instruction issue" in w else "hbm"}
+                           for k, w, b, _ in ops]},
               sys.stdout)
     print()
 

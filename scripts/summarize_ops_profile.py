@@ -61,7 +61,10 @@ def main():
             ms = dur / 1e6
             gbps = alg / dur
             total = (rd or 0) + (wr or 0)
-            f.write(f"| `{k['name']}` | {k['what']} | {ms:.4f} | {gbps:.0f} | {gbps / 8000:.3f} | "
+            # a kernel bound by instruction issue is priced in <tag>_valu_summary.md, not here
+            frac = f"{gbps / 8000:.3f}" if k.get("bound", "hbm") == "hbm" else \
+                f"not HBM-bound: `{tag}_valu_summary.md`"
+            f.write(f"| `{k['name']}` | {k['what']} | {ms:.4f} | {gbps:.0f} | {frac} | "
                     f"{rd:.4e} | {wr:.4e} | {total / alg:.4f} | {row['VGPR_Count']} | "
                     f"{row['LDS_Block_Size']} |\n")
     print(open(out).read())
