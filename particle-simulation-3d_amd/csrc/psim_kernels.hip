@@ -511,18 +511,14 @@ struct KernargAttractors {
 // Stores the wave's 256 colour quads (`col` of every lane with `live`) to the colour array
 // of groups g0 .. g0+63 through the wave's LDS tile `t`, 1 KiB of consecutive bytes per
 // store instruction.  Must be reached by the whole wave.
+// The second half: the whole wave stores what its lanes have written into the tile
+// (t[j][lane] = colour of the lane's particle j).
 template <int MODE>
-__device__ __forceinline__ void store_colours_transposed(f32x4 (*t)[PSIM_COLOUR_ROW],
-                                                         f32x4 *col4, uint32_t g0, uint32_t lane,
-                                                         bool live, uint32_t ngroups,
-                                                         const f32x4 (&col)[4])
+__device__ __forceinline__ void store_staged_colours(f32x4 (*t)[PSIM_COLOUR_ROW], f32x4 *col4,
+                                                     uint32_t g0, uint32_t lane, uint32_t ngroups)
 {
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[j][lane] = col[j];
-    }
     // LDS operations of one wave execute in order; the fences only pin the compiler's
-    // ordering of the writes above against the reads below.
+    // ordering of the lanes' writes against the reads below.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -542,6 +538,19 @@ __device__ __forceinline__ void store_colours_transposed(f32x4 (*t)[PSIM_COLOUR_
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                              // a later call rewrites the tile
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_colours_transposed(f32x4 (*t)[PSIM_COLOUR_ROW],
+                                                         f32x4 *col4, uint32_t g0, uint32_t lane,
+                                                         bool live, uint32_t ngroups,
+                                                         const f32x4 (&col)[4])
+{
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j][lane] = col[j];
+    }
+    store_staged_colours<MODE>(t, col4, g0, lane, ngroups);
 }
 
 template <int CM, int FORCE, int MODE>
@@ -701,11 +710,16 @@ struct BatchParams {
     psim_sim_params p[PSIM_BATCH_STEPS];
 };
 
+// `staged` (N == 4): the lane's row of the wave's colour tile; the colours of step
+// `colour_step` go there at once instead of staying in 16 registers for the rest of the
+// batch (62 instead of 78 registers: 8 instead of 6 waves per SIMD).  `col` (N == 1) takes
+// the tail particle's.
 template <int N>
 __device__ __forceinline__ void step_batch(float (&a)[N], float (&b)[N], float (&c)[N],
                                            float (&d)[N], float (&e)[N], float (&f)[N],
-                                           f32x4 (&col)[N], const BatchParams &bp,
-                                           uint32_t nsteps, int colour_step)
+                                           f32x4 (*staged)[PSIM_COLOUR_ROW], uint32_t lane,
+                                           f32x4 *col, const BatchParams &bp, uint32_t nsteps,
+                                           int colour_step)
 {
     for (uint32_t k = 0; k < nsteps; ++k) {
         const psim_sim_params &p = bp.p[k];
@@ -713,9 +727,12 @@ __device__ __forceinline__ void step_batch(float (&a)[N], float (&b)[N], float (
         else step<0, N>(a, b, c, d, e, f, p, nullptr, 0);
         if ((int)k == colour_step) {
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                col[j] = p.color_mode == 1 ? colour<1>(a[j], b[j], c[j], d[j], e[j], f[j], p)
-                                           : colour<2>(a[j], b[j], c[j], d[j], e[j], f[j], p);
+            for (int j = 0; j < N; ++j) {
+                const f32x4 v = p.color_mode == 1 ? colour<1>(a[j], b[j], c[j], d[j], e[j], f[j], p)
+                                                  : colour<2>(a[j], b[j], c[j], d[j], e[j], f[j], p);
+                if constexpr (N == 4) staged[j][lane] = v;
+                else col[j] = v;
+            }
         }
     }
 }
@@ -740,7 +757,6 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs
          g0 += stride) {
         const uint32_t g = g0 + lane;
         const bool live = g < ngroups;
-        f32x4 col[4];
         if (live) {
             f32x4 x = ld<NT>(px4 + g), y = ld<NT>(py4 + g), z = ld<NT>(pz4 + g);
             f32x4 u = ld<NT>(vx4 + g), v = ld<NT>(vy4 + g), w = ld<NT>(vz4 + g);
@@ -750,7 +766,8 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs
                 a[j] = x[j]; b[j] = y[j]; c[j] = z[j];
                 d[j] = u[j]; e[j] = v[j]; f[j] = w[j];
             }
-            step_batch<4>(a, b, c, d, e, f, col, bp, nsteps, colour_step);
+            step_batch<4>(a, b, c, d, e, f, tile[threadIdx.x >> 6], lane, nullptr, bp, nsteps,
+                          colour_step);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 x[j] = a[j]; y[j] = b[j]; z[j] = c[j];
@@ -761,8 +778,7 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs
             st_state<MODE>(vy4, g0, ngroups, lane, v); st_state<MODE>(vz4, g0, ngroups, lane, w);
         }
         if (colour_step >= 0)                                     // uniform over the grid
-            store_colours_transposed<MODE>(tile[threadIdx.x >> 6], col4, g0, lane, live, ngroups,
-                                           col);
+            store_staged_colours<MODE>(tile[threadIdx.x >> 6], col4, g0, lane, ngroups);
     }
 
     // Tail: particles 4*ngroups .. n-1.
@@ -771,7 +787,7 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_batch_kernel(SoaPtrs
         float x[1] = {s.px[i]}, y[1] = {s.py[i]}, z[1] = {s.pz[i]};
         float u[1] = {s.vx[i]}, v[1] = {s.vy[i]}, w[1] = {s.vz[i]};
         f32x4 col[1];
-        step_batch<1>(x, y, z, u, v, w, col, bp, nsteps, colour_step);
+        step_batch<1>(x, y, z, u, v, w, nullptr, 0u, col, bp, nsteps, colour_step);
         s.px[i] = x[0]; s.py[i] = y[0]; s.pz[i] = z[0];
         s.vx[i] = u[0]; s.vy[i] = v[0]; s.vz[i] = w[0];
         if (colour_step >= 0) col4[i] = col[0];
