@@ -430,7 +430,7 @@ int psim_launch_shape(uint32_t count, uint32_t n_attractors, psim_launch_shape_i
  * result must equal psim_launch_shape's resident_per_cu.  lds_bytes_per_workgroup (optional)
  * receives the LDS one workgroup takes: what the kernel declares plus the reservation.  (A
  * kernel that declares more than the reservation asks for -- colour modes 1 / 2 with a list
- * of 5 to 8 attractors: 10496 B against 10240 -- is held by its own LDS: 15 per CU, not 16.) */
+ * of 5 to 8 attractors: 11520 B against 10240 -- is held by its own LDS: 14 per CU, not 16.) */
 int psim_launch_occupancy(psim_handle *h, uint32_t n_attractors, uint32_t color_mode,
                           uint32_t *workgroups_per_cu, uint32_t *lds_bytes_per_workgroup);
 

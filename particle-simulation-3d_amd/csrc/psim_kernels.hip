@@ -316,31 +316,32 @@ __device__ __forceinline__ void wave_lds_sync()
 // `queue` the wave's PSIM_PAIR_QUEUE quads of LDS.
 __device__ __forceinline__ void attract_list_queued(float (&px)[4], float (&py)[4], float (&pz)[4],
                                                     float (&vx)[4], float (&vy)[4], float (&vz)[4],
-                                                    const psim_attractor *alist, uint32_t na,
+                                                    const psim_attractor *alist,
+                                                    const f32x4 *tests, uint32_t na,
                                                     float dt, f32x4 *queue, uint32_t lane,
                                                     bool live)
 {
     for (uint32_t c0 = 0; c0 < na; c0 += PSIM_PAIR_CHUNK) {
         const uint32_t cn = (na - c0) < PSIM_PAIR_CHUNK ? (na - c0) : PSIM_PAIR_CHUNK;
         uint32_t mask[4] = {0u, 0u, 0u, 0u};
+        // `tests` holds one 16-byte record per attractor, {position, threshold}, the
+        // threshold 0 for an attractor that is switched off (no squared distance is below
+        // it): one LDS read and no branch per attractor, so that the reads of the unrolled
+        // loop below go out ahead of the arithmetic instead of one round trip at a time.
         const auto test = [&](uint32_t a) {                  // hits of attractor c0 + a
-            const psim_attractor &at = alist[c0 + a];
-            if (at.active > 0) {
-                const float thr = __uint_as_float(at._pad[0]);
-                // two particles per packed fp32 instruction (each lane of a packed operation
-                // rounds like the scalar one; nothing is fused)
-                const f32x2 ax = {at.position[0], at.position[0]},
-                            ay = {at.position[1], at.position[1]},
-                            az = {at.position[2], at.position[2]};
+            const f32x4 at = tests[c0 + a];
+            const float thr = at[3];
+            // two particles per packed fp32 instruction (each lane of a packed operation
+            // rounds like the scalar one; nothing is fused)
+            const f32x2 ax = {at[0], at[0]}, ay = {at[1], at[1]}, az = {at[2], at[2]};
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x2 dx = ax - f32x2{px[2 * h], px[2 * h + 1]},
-                                dy = ay - f32x2{py[2 * h], py[2 * h + 1]},
-                                dz = az - f32x2{pz[2 * h], pz[2 * h + 1]};
-                    const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
-                    mask[2 * h] |= ((live && d2[0] < thr) ? 1u : 0u) << a;       // cpu.rs:79
-                    mask[2 * h + 1] |= ((live && d2[1] < thr) ? 1u : 0u) << a;
-                }
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 dx = ax - f32x2{px[2 * h], px[2 * h + 1]},
+                            dy = ay - f32x2{py[2 * h], py[2 * h + 1]},
+                            dz = az - f32x2{pz[2 * h], pz[2 * h + 1]};
+                const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+                mask[2 * h] |= ((live && d2[0] < thr) ? 1u : 0u) << a;           // cpu.rs:79
+                mask[2 * h + 1] |= ((live && d2[1] < thr) ? 1u : 0u) << a;
             }
         };
         // The chunk's first attractor alone tells (nearly for free: four scalar population
@@ -353,6 +354,7 @@ __device__ __forceinline__ void attract_list_queued(float (&px)[4], float (&py)[
             first_hits += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mask[j] & 1u));
         uint32_t total = PSIM_PAIR_QUEUE + 1u, base = 0;
         if (first_hits * cn <= PSIM_PAIR_QUEUE) {
+#pragma unroll 2
             for (uint32_t a = 1; a < cn; ++a) test(a);
             const uint32_t hits =
                 (uint32_t)(__builtin_popcount(mask[0]) + __builtin_popcount(mask[1]) +
@@ -562,6 +564,11 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
 {
     constexpr bool NT = MODE == PSIM_ACCESS_STREAM;          // non-temporal loads
     const psim_attractor *alist = nullptr;
+    [[maybe_unused]] f32x4 *lds_tests = nullptr;              // see attract_list_queued()
+    if constexpr (FORCE == 4) {
+        __shared__ f32x4 test_records[PSIM_MAX_ATTRACTORS];
+        lds_tests = test_records;
+    }
     if constexpr (FORCE == 2 || FORCE == 4) {
         // Stage the attractor list (<= 2 KiB) into LDS once per workgroup; the queued form
         // also takes a list that came in the kernel arguments (attr_dev == nullptr).
@@ -574,9 +581,14 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
             reinterpret_cast<uint32_t *>(lds_attr)[w] = src[w];
         __syncthreads();
         static_assert(PSIM_MAX_ATTRACTORS <= PSIM_UPDATE_BLOCK, "one lane per attractor");
-        if (threadIdx.x < na)                                 // one lane per attractor
-            lds_attr[threadIdx.x]._pad[0] =
-                __float_as_uint(psim_in_range_threshold(lds_attr[threadIdx.x].radius * 2.0f));
+        if (threadIdx.x < na) {                               // one lane per attractor
+            psim_attractor &at = lds_attr[threadIdx.x];
+            const float thr = psim_in_range_threshold(at.radius * 2.0f);
+            at._pad[0] = __float_as_uint(thr);
+            if constexpr (FORCE == 4)
+                lds_tests[threadIdx.x] = f32x4{at.position[0], at.position[1], at.position[2],
+                                               at.active > 0 ? thr : 0.0f};
+        }
         __syncthreads();
         alist = lds_attr;
     } else if constexpr (FORCE == 3) {
@@ -613,7 +625,7 @@ __global__ void __launch_bounds__(PSIM_UPDATE_BLOCK) update_kernel(SoaPtrs s, ui
                 d[j] = u[j]; e[j] = v[j]; f[j] = w[j];
             }
             apply_gravity<4>(e, p);
-            attract_list_queued(a, b, c, d, e, f, alist, na, p.delta_time,
+            attract_list_queued(a, b, c, d, e, f, alist, lds_tests, na, p.delta_time,
                                 queue[threadIdx.x >> 6], lane, live);
             integrate<4>(a, b, c, d, e, f, p);
             if (live) {
@@ -866,7 +878,8 @@ static UpdateLaunch pick_nt(const LaunchTuning &t)
     // The reservation counts the LDS the kernel itself declares.
     constexpr uint32_t used = (CM != 0 ? (PSIM_UPDATE_BLOCK / 64) * 4 * PSIM_COLOUR_ROW * 16 : 0) +
                               (FORCE == 2 || FORCE == 4 ? PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) : 0) +
-                              (FORCE == 4 ? (PSIM_UPDATE_BLOCK / 64) * PSIM_PAIR_QUEUE * 16 : 0);
+                              (FORCE == 4 ? (PSIM_UPDATE_BLOCK / 64) * PSIM_PAIR_QUEUE * 16 +
+                                                PSIM_MAX_ATTRACTORS * 16 : 0);
     uint32_t want = CM != 0 ? t.reserve_lds_colour : t.reserve_lds;
     // A list of one attractor in the kernel arguments carries the loop of the list kernels:
     // 7 workgroups per CU (0.741 ms at 100 M particles) rather than the 6 of the plain
