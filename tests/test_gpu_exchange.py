@@ -77,3 +77,44 @@ def test_plain_c_host_of_the_exchange(tmp_path):
         want = T.oracle_update_aos(want, params, 1, a)
     assert got == T.oracle_checksum_soa(T.aos_to_soa(want))
     print(f"C host: {host_us:.1f} us of host time, {device_us:.1f} us of device time per step")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world):
+    """The exchange's logic for a world larger than one -- every rank's place in the receive
+    lists, the ring, the list length the kernel gets, shards of one global array, ranks that
+    really wait for the rendezvous file -- with `world` C host processes sharing GPU 0.  RCCL
+    itself refuses that, so PSIM_RCCL_LIBRARY points the exchange at tests/cpp/libfake_rccl.so,
+    a test double whose all-gather goes through shared memory (see its header); the real
+    collective runs in the cases above (one rank) and in bench.py on a multi-GPU node."""
+    cpp_dir = os.path.join(T.ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp_dir, "exchange_loop", "libfake_rccl.so"],
+                          stdout=subprocess.DEVNULL)
+    n, steps = 50_003, 20                                # 40 steps in all: the ring goes round
+    env = dict(os.environ, PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"))
+    procs = [subprocess.Popen([os.path.join(cpp_dir, "exchange_loop"), str(r), str(world), "0",
+                               str(n), str(steps), str(tmp_path / "id")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in reversed(range(world))]            # rank 0 last: the others wait for its file
+    outs = {}
+    for r, p in zip(reversed(range(world)), procs):
+        out, err = p.communicate(timeout=150)
+        assert p.returncode == 0, f"rank {r}: {err[-2000:]}"
+        outs[r] = [int(v) for v in out.strip().splitlines()[-1].split()[2:8]]
+    params = T.make_params(delta_time=0.016, gravity=0.25, color_mode=0, mouse_force=5.0,
+                           mouse_radius=10.0, is_mouse_dragging=0, damping=0.99,
+                           max_dist_for_color=50.0)
+
+    def attractors(t):
+        a = np.zeros(world, dtype=psim.ATTRACTOR_DTYPE)
+        for k in range(world):
+            a["position"][k] = (-40.0 + 10.0 * k + 0.25 * (t % 64), 30.0 - 0.5 * (t % 32),
+                                -20.0 + 5.0 * k)
+        a["force"], a["radius"], a["active"] = 40.0, 25.0, 1
+        return a
+
+    for r in range(world):
+        want = T.oracle_gen_uniform_aos(r * n, n)
+        for t in range(2 * steps):
+            want = T.oracle_update_aos(want, params, 1, attractors(t))
+        assert outs[r] == T.oracle_checksum_soa(T.aos_to_soa(want)), f"rank {r} of {world}"
