@@ -197,14 +197,16 @@ class Watchdog:
         self._signal.set_wakeup_fd(self._old_fd)
 
 
-def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, steps=200, warmup=20):
+def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, steps=200, warmup=20,
+                   rehearsal=False):
     """The config-5 step (6.25 M particles per rank, one moving attractor per rank, RCCL
     all-gather every step through psim_exchange_*) over all ranks, untimed by the headline:
     what the collective delivers (bit for bit against the closed-form paths) and what a step
     costs against the same kernel fed from a host list."""
     import numpy as np
     n = 6_250_000
-    ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8, device="cuda")
+    dev = "cpu" if rehearsal else "cuda"             # a rehearsal talks over gloo
+    ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8, device=dev)
     if rank == 0:
         ident.copy_(torch.frombuffer(bytearray(psim.exchange_unique_id()), dtype=torch.uint8))
     dist.broadcast(ident, 0)
@@ -213,7 +215,10 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
     for _ in range(warmup):
         runner.step()
     runner.finish()
-    dist.barrier(device_ids=[local_rank])
+    if rehearsal:
+        dist.barrier()
+    else:
+        dist.barrier(device_ids=[local_rank])
     runner.sim.timer_start()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -234,7 +239,7 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
     kernel_ms = runner.sim.timer_stop()
     runner.close()
     t = torch.tensor([wall / steps * 1e6, device_ms / steps * 1e3, kernel_ms / steps * 1e3,
-                      0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+                      0.0 if ok else 1.0], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     w, d, k, bad = (float(v) for v in t.tolist())
     return {
@@ -438,7 +443,10 @@ def main():
             line = dict(out, exchange_check=extra) if extra is not None else out
             os.write(json_fd, (json.dumps(line) + "\n").encode())
 
-    if world > 1 and workload == "single" and not rehearsal and not args.no_exchange_check:
+    # (a rehearsal shares one GPU between the ranks, which RCCL refuses: it runs the check only
+    # when PSIM_RCCL_LIBRARY names a stand-in, as the tests do)
+    if world > 1 and workload == "single" and not args.no_exchange_check and \
+            (not rehearsal or os.environ.get("PSIM_RCCL_LIBRARY")):
         # The headline numbers are final at this point.  Whatever happens to the extra run --
         # an error, a hang, a rank killed by the launcher -- the line still goes out.
         sim.close()
@@ -446,7 +454,8 @@ def main():
         guard = Watchdog(EXCHANGE_CHECK_SECONDS,
                          lambda why: emit({"error": f"exchange check abandoned: {why}"}))
         try:
-            check = exchange_check(psim, par, torch, dist, rank, world, local_rank, params)
+            check = exchange_check(psim, par, torch, dist, rank, world, local_rank, params,
+                                   rehearsal=rehearsal)
         except Exception as e:                       # noqa: BLE001 -- reported in the line
             check = {"error": f"{type(e).__name__}: {e}"}
         guard.cancel()

@@ -214,8 +214,9 @@ PSIM_API void psim_exchange_destroy(psim_exchange *x)
 {
     if (!x) return;
     (void)hipSetDevice(x->device);
-    if (x->h) (void)psim_sync(x->h);
-    if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+    // Kernels on the handle's stream may still read the lists.  The handle is the caller's and
+    // may already be gone, so it is not touched here: the whole device is waited for instead.
+    (void)hipDeviceSynchronize();
     if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
     for (hipEvent_t e : x->gathered)
         if (e) (void)hipEventDestroy(e);
@@ -282,7 +283,6 @@ PSIM_API int psim_exchange_create(psim_exchange **out, psim_handle *h,
     x->world = world;
     const int rc = create_impl(x, id);
     if (rc != PSIM_OK) {
-        x->h = nullptr;                              // the handle stays the caller's
         psim_exchange_destroy(x);
         return rc;
     }

@@ -156,3 +156,31 @@ def test_strong_scaling_rehearsal():
     assert out["config"]["total_particles"] == total and out["config"]["particles_per_gpu"] == 1_000_000
     assert abs(out["value"] - total * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-6
     assert "exchange_check" not in out               # a rehearsal cannot run RCCL
+
+
+def test_multi_gpu_exchange_check_rehearsal():
+    """What bench.py appends to a multi-GPU run of a single-attractor configuration -- the
+    config-5 exchange over all ranks, outside the timed region -- rehearsed with two ranks on
+    one GPU: gloo between the ranks and tests/cpp/libfake_rccl.so (a shared-memory test double,
+    RCCL refuses two ranks on one device) under the library's exchange.  Checks that the line
+    carries the check and that the lists the ranks received are the closed-form paths."""
+    cpp_dir = os.path.join(T.ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp_dir, "libfake_rccl.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, PSIM_BENCH_REHEARSAL="1",
+               PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(T.ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "2", "--particles", "1000000"],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:1000]
+    out = json.loads(lines[0])
+    check = out["exchange_check"]
+    assert "error" not in check, check
+    assert check["lists_match_closed_form"] is True
+    assert check["us_per_step_device"] > 0 and check["us_per_step_kernel_only"] > 0
+    assert out["n_gpus"] == 2 and out["value"] > 0
