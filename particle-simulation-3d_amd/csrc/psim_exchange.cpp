@@ -160,8 +160,8 @@ PSIM_API int psim_exchange_unique_id(uint8_t id[PSIM_EXCHANGE_ID_BYTES])
     return PSIM_OK;
 }
 
-// The id as a file: `make` (rank 0) writes it under a temporary name and renames it into
-// place, so a reader never sees a partial id; the others poll for it.
+// The id as a file: rank 0 makes it, writes it under a temporary name and renames it into
+// place, so a reader never sees a partial id; the other ranks poll for the file.
 PSIM_API int psim_exchange_rendezvous_file(const char *path, int rank,
                                            uint8_t id[PSIM_EXCHANGE_ID_BYTES],
                                            uint32_t timeout_ms)
