@@ -126,7 +126,24 @@ public:
         check(psim_update_multi(h_, &params, attractors_device, n));
     }
 
+    // update_multi for callers that cannot allocate (HIP graph capture, serving loops): the
+    // list goes through the library's static 2 KiB device array; <= 64 attractors.
+    void update_multi_noalloc(const SimParams &params, const std::vector<Attractor> &attractors)
+    {
+        check(psim_update_multi_host_noalloc(h_, &params, attractors.data(),
+                                             static_cast<uint32_t>(attractors.size())));
+    }
+
     void sync() { check(psim_sync(h_)); }
+
+    // Workgroups of this simulation's update kernel that one CU holds at once, as the runtime
+    // reports it (the residency cap is worth a fifth of the update's bandwidth).
+    uint32_t launch_occupancy(uint32_t n_attractors = 1, uint32_t color_mode = 0)
+    {
+        uint32_t workgroups = 0;
+        check(psim_launch_occupancy(h_, n_attractors, color_mode, &workgroups, nullptr));
+        return workgroups;
+    }
 
     // `fn resize_buffer(&mut self, device, queue, new_count, generation_mode)`
     void resize_buffer(uint32_t new_count, SphereGeneration generation_mode)
@@ -206,6 +223,14 @@ public:
         return step;
     }
 
+    // One file written by several shards: checkpoint_begin(path) once, save_checkpoint on
+    // every shard, then commit_checkpoint on any one of them once all have returned.
+    static void checkpoint_begin(const std::string &path) { check(psim_checkpoint_begin(path.c_str())); }
+    void commit_checkpoint(const std::string &path, uint64_t step = 0)
+    {
+        check(psim_checkpoint_commit(h_, path.c_str(), step));
+    }
+
     psim_handle *handle() { return h_; }
 
 private:
@@ -214,6 +239,63 @@ private:
         if (rc != PSIM_OK) throw Error(rc, psim_last_error());
     }
     psim_handle *h_ = nullptr;
+};
+
+// HIP devices this process sees.
+inline int device_count() { return psim_device_count(); }
+
+// The multi-attractor step of a set sharded over one process per GPU (psim_exchange_*): every
+// rank owns one attractor; step() all-gathers the ranks' records with RCCL on a stream of its
+// own and applies all of them to the particles of `sim`, which must outlive the exchange.
+class HipAttractorExchange {
+public:
+    using Id = std::vector<uint8_t>;                 // PSIM_EXCHANGE_ID_BYTES bytes
+
+    // ONE rank makes the id; the caller hands it to every rank ...
+    static Id unique_id()
+    {
+        Id id(PSIM_EXCHANGE_ID_BYTES);
+        check(psim_exchange_unique_id(id.data()));
+        return id;
+    }
+    // ... or all ranks meet at a file that rank 0 publishes (fresh path per run).
+    static Id rendezvous_file(const std::string &path, int rank, uint32_t timeout_ms = 60000)
+    {
+        Id id(PSIM_EXCHANGE_ID_BYTES);
+        check(psim_exchange_rendezvous_file(path.c_str(), rank, id.data(), timeout_ms));
+        return id;
+    }
+
+    HipAttractorExchange(HipParticleSimulation &sim, const Id &id, int rank, int world)
+    {
+        if (id.size() != PSIM_EXCHANGE_ID_BYTES) throw Error(PSIM_ERR_INVALID, "the id is 128 bytes");
+        check(psim_exchange_create(&x_, sim.handle(), id.data(), rank, world));
+    }
+    ~HipAttractorExchange() { psim_exchange_destroy(x_); }
+    HipAttractorExchange(const HipAttractorExchange &) = delete;
+    HipAttractorExchange &operator=(const HipAttractorExchange &) = delete;
+
+    // Collective and asynchronous: this rank's attractor joins the others', all are applied.
+    void step(const SimParams &params, const Attractor &mine)
+    {
+        check(psim_exchange_step(x_, &params, &mine));
+    }
+    void sync() { check(psim_exchange_sync(x_)); }
+    std::vector<Attractor> last_list()
+    {
+        std::vector<Attractor> out(static_cast<size_t>(psim_exchange_world(x_)));
+        check(psim_exchange_last_list(x_, out.data()));
+        return out;
+    }
+    int rank() const { return psim_exchange_rank(x_); }
+    int world() const { return psim_exchange_world(x_); }
+
+private:
+    static void check(int rc)
+    {
+        if (rc != PSIM_OK) throw Error(rc, psim_last_error());
+    }
+    psim_exchange *x_ = nullptr;
 };
 
 // One particle set over several GPUs, driven from one process (psim_group_*): shard k lives
