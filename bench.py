@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--exchange", choices=["native", "torch"], default="native",
                     help="multi workload: the library's own RCCL exchange (psim_exchange_*) or "
                          "torch.distributed's all_gather_into_tensor")
+    ap.add_argument("--pacing", choices=["host", "device"], default="host",
+                    help="multi workload with --exchange native: who waits for a step's "
+                         "all-gather, the calling thread (kernels then run back to back) or "
+                         "the kernel's stream (see psim_exchange_set_pacing)")
     ap.add_argument("--lookahead", type=int, default=1,
                     help="multi workload with --exchange torch: steps of attractor state "
                          "exchanged per all-gather (1 = one collective per step)")
@@ -226,7 +230,19 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
     device_ms = runner.sim.timer_stop()
     runner.finish()
     wall = time.perf_counter() - t0
-    last = warmup + steps - 1
+    # the same again with the calling thread waiting for each gather (kernels back to back)
+    runner.exchange.set_pacing(psim.EXCHANGE_HOST_PACED)
+    for _ in range(warmup):
+        runner.step()
+    runner.finish()
+    barrier = dist.barrier if rehearsal else (lambda: dist.barrier(device_ids=[local_rank]))
+    barrier()
+    runner.sim.timer_start()
+    for _ in range(steps):
+        runner.step()
+    host_paced_ms = runner.sim.timer_stop()
+    runner.finish()
+    last = 2 * (warmup + steps) - 1
     ok = runner.exchange.last_list().tobytes() == par.attractors_at(last, world).tobytes()
     # the same kernel without the exchange: the list handed over by the host
     table = par.attractors_at(last, world)
@@ -239,15 +255,17 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
     kernel_ms = runner.sim.timer_stop()
     runner.close()
     t = torch.tensor([wall / steps * 1e6, device_ms / steps * 1e3, kernel_ms / steps * 1e3,
-                      0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+                      0.0 if ok else 1.0, host_paced_ms / steps * 1e3],
+                     dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    w, d, k, bad = (float(v) for v in t.tolist())
+    w, d, k, bad, hp = (float(v) for v in t.tolist())
     return {
         "workload": f"{n} particles per GPU, {world} moving attractors, psim_exchange_step "
                     f"(RCCL all-gather of 32 B per rank, double-buffered) x {steps} steps",
         "lists_match_closed_form": bad == 0.0,
         "us_per_step_wall": w,
         "us_per_step_device": d,
+        "us_per_step_device_host_paced": hp,
         "us_per_step_kernel_only": k,
         "aggregation": "max over ranks",
     }
@@ -328,7 +346,7 @@ def main():
             else:
                 unique_id = psim.exchange_unique_id()
             runner = par.NativeMultiAttractorRunner(n, rank, world, local_rank, params, unique_id,
-                                                    first=first, total=total)
+                                                    first=first, total=total, pacing=args.pacing)
         else:
             runner = par.MultiAttractorRunner(n, rank, world, local_rank, params,
                                               lookahead=args.lookahead, first=first, total=total)
@@ -388,7 +406,7 @@ def main():
             every = "every step" if args.lookahead == 1 or args.exchange == "native" else \
                 f"every {args.lookahead} steps ({args.lookahead} x 32 B per rank)"
             sharding = (f"contiguous index ranges x{world}, all-gather of 32 B per rank {every} "
-                        f"({'psim_exchange_step: RCCL behind the C ABI' if args.exchange == 'native' else 'torch.distributed'})")
+                        f"({'psim_exchange_step: RCCL behind the C ABI, ' + args.pacing + '-paced' if args.exchange == 'native' else 'torch.distributed'})")
             kernel = ("psim::update_kernel<colour 0, attractor list staged in LDS> "
                       "(launch_ms here also holds the waits for the per-step all-gather)")
             what = f"{world} moving attractors (one per rank, r 10 f 5) all-gathered over RCCL"

@@ -524,6 +524,20 @@ void psim_exchange_destroy(psim_exchange *x);
 int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
                        const psim_attractor *mine);
 
+/* How a step's kernel is ordered behind its all-gather.
+ * PSIM_EXCHANGE_DEVICE_PACED (default): the handle's stream waits for the gather's event; the
+ * call returns at once, and the wait costs a few microseconds of device time per step.
+ * PSIM_EXCHANGE_HOST_PACED: the calling thread waits for the gather -- which runs under the
+ * previous step's kernel -- and then enqueues the kernel with nothing in front of it, so kernels
+ * run back to back; the call returns once the gather has finished (the kernel still runs
+ * asynchronously).  Pays when a step's kernel takes longer than the gather plus the host's
+ * work, i.e. for shards of millions of particles.  All ranks may choose independently. */
+enum {
+    PSIM_EXCHANGE_DEVICE_PACED = 0,
+    PSIM_EXCHANGE_HOST_PACED   = 1
+};
+int psim_exchange_set_pacing(psim_exchange *x, int pacing);
+
 /* Waits for everything the exchange and its handle have enqueued. */
 int psim_exchange_sync(psim_exchange *x);
 

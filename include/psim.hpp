@@ -280,6 +280,8 @@ public:
     {
         check(psim_exchange_step(x_, &params, &mine));
     }
+    // PSIM_EXCHANGE_DEVICE_PACED (default) or PSIM_EXCHANGE_HOST_PACED
+    void set_pacing(int pacing) { check(psim_exchange_set_pacing(x_, pacing)); }
     void sync() { check(psim_exchange_sync(x_)); }
     std::vector<Attractor> last_list()
     {

@@ -188,6 +188,7 @@ ABI = {
     "psim_exchange_create": (c_int, [POINTER(_P), _P, _P, c_int, c_int]),
     "psim_exchange_destroy": (None, [_P]),
     "psim_exchange_step": (c_int, [_P, POINTER(SimParams), _P]),
+    "psim_exchange_set_pacing": (c_int, [_P, c_int]),
     "psim_exchange_sync": (c_int, [_P]),
     "psim_exchange_last_list": (c_int, [_P, _P]),
     "psim_exchange_world": (c_int, [_P]),
@@ -566,6 +567,7 @@ class HipParticleGroup:
 
 
 EXCHANGE_ID_BYTES = 128
+EXCHANGE_DEVICE_PACED, EXCHANGE_HOST_PACED = 0, 1
 
 
 def exchange_unique_id():
@@ -612,6 +614,10 @@ class HipAttractorExchange:
         rc = self._lib.psim_exchange_step(self._x, params_ref, mine_address)
         if rc:
             _check(rc)
+
+    def set_pacing(self, pacing):
+        """EXCHANGE_DEVICE_PACED (default) or EXCHANGE_HOST_PACED: see include/psim.h."""
+        _check(self._lib.psim_exchange_set_pacing(self._x, int(pacing)))
 
     def sync(self):
         _check(self._lib.psim_exchange_sync(self._x))

@@ -140,6 +140,7 @@ struct psim_exchange {
     hipEvent_t gathered[16] = {};                     // per list: its all-gather has finished
     hipEvent_t kernel_done[2] = {nullptr, nullptr};   // per half: its last kernel has finished
     uint64_t t = 0;                                   // steps taken
+    bool host_paced = false;                          // see psim_exchange_set_pacing()
 };
 
 namespace {
@@ -309,11 +310,26 @@ PSIM_API int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
     RCCL_TRY(r, r->AllGather(list + x->rank, list, kRecordWords, ncclInt32, x->comm,
                              x->comm_stream));       // in place: own record already sits at [rank]
     HIP_TRY(hipEventRecord(x->gathered[slot], x->comm_stream));
-    HIP_TRY(hipStreamWaitEvent(compute, x->gathered[slot], 0));
+    if (x->host_paced) {
+        // The HOST waits for the gather (which runs under the previous step's kernel), so the
+        // kernel goes into its queue with nothing in front of it but the previous kernel.
+        HIP_TRY(hipEventSynchronize(x->gathered[slot]));
+    } else {
+        HIP_TRY(hipStreamWaitEvent(compute, x->gathered[slot], 0));
+    }
     rc = psim_update_multi(x->h, params, list, (uint32_t)x->world);
     if (rc != PSIM_OK) return rc;
     if (slot % kHalf == kHalf - 1) HIP_TRY(hipEventRecord(x->kernel_done[half], compute));
     ++x->t;
+    return PSIM_OK;
+}
+
+PSIM_API int psim_exchange_set_pacing(psim_exchange *x, int pacing)
+{
+    if (!x) return psim_fail(PSIM_ERR_INVALID, "null exchange");
+    if (pacing != PSIM_EXCHANGE_DEVICE_PACED && pacing != PSIM_EXCHANGE_HOST_PACED)
+        return psim_fail(PSIM_ERR_INVALID, "unknown pacing %d", pacing);
+    x->host_paced = pacing == PSIM_EXCHANGE_HOST_PACED;
     return PSIM_OK;
 }
 

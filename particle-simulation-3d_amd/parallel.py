@@ -102,11 +102,13 @@ class NativeMultiAttractorRunner:
     lists, then the multi-attractor kernel): the same steps as MultiAttractorRunner without torch in the data
     path.  `unique_id` is the 128-byte communicator id every rank received from the one that
     made it (HipParticleSimulation-side helpers: exchange_unique_id, exchange_rendezvous_file).
-    Attractor `rank` follows the closed-form path of attractor_at()."""
+    Attractor `rank` follows the closed-form path of attractor_at().  `pacing` "host" makes
+    the calling thread wait for each gather so that the kernels run back to back (see
+    psim_exchange_set_pacing in include/psim.h)."""
 
     def __init__(self, particles_per_rank, rank, world, local_rank, params, unique_id,
-                 force=5.0, radius=10.0, first=None, total=None):
-        from . import HipAttractorExchange
+                 force=5.0, radius=10.0, first=None, total=None, pacing="device"):
+        from . import HipAttractorExchange, EXCHANGE_DEVICE_PACED, EXCHANGE_HOST_PACED
         self.rank, self.world, self.params = rank, world, params
         self.force, self.radius = force, radius
         # this rank's shard [first, first + particles_per_rank) of `total` (default: equal shards)
@@ -115,6 +117,8 @@ class NativeMultiAttractorRunner:
             world * particles_per_rank if total is None else total,
             GEN_UNIFORM, device_id=local_rank)
         self.exchange = HipAttractorExchange(self.sim, unique_id, rank, world)
+        self.exchange.set_pacing({"device": EXCHANGE_DEVICE_PACED,
+                                  "host": EXCHANGE_HOST_PACED}[pacing])
         self.t = 0
         self._path = None          # own attractor records for steps [_path_first, +len)
         self._path_first = 0

@@ -175,6 +175,12 @@ impl ShardedRank {
         check(unsafe { psim_exchange_step(self.exchange, params, mine) });
     }
 
+    /// A headless rank has nothing else to do between frames: let the thread wait for each
+    /// gather, so that the kernels run back to back (`PSIM_EXCHANGE_HOST_PACED`).
+    pub fn pace_from_host(&mut self) {
+        check(unsafe { psim_exchange_set_pacing(self.exchange, PSIM_EXCHANGE_HOST_PACED) });
+    }
+
     pub fn sync(&mut self) {
         check(unsafe { psim_exchange_sync(self.exchange) });
     }

@@ -128,6 +128,8 @@ pub const PSIM_COLOR_KEEP: c_int = 0;
 pub const PSIM_COLOR_RESET: c_int = 1;
 pub const PSIM_RESIZE_REGENERATE: c_int = 0;
 pub const PSIM_RESIZE_APPEND: c_int = 1;
+pub const PSIM_EXCHANGE_DEVICE_PACED: c_int = 0;
+pub const PSIM_EXCHANGE_HOST_PACED: c_int = 1;
 
 #[link(name = "psim_hip")]
 extern "C" {
@@ -196,6 +198,7 @@ extern "C" {
     pub fn psim_exchange_create(out: *mut *mut PsimExchange, h: *mut PsimHandle, id: *const u8, rank: c_int, world: c_int) -> c_int;
     pub fn psim_exchange_destroy(x: *mut PsimExchange);
     pub fn psim_exchange_step(x: *mut PsimExchange, params: *const PsimSimParams, mine: *const PsimAttractor) -> c_int;
+    pub fn psim_exchange_set_pacing(x: *mut PsimExchange, pacing: c_int) -> c_int;
     pub fn psim_exchange_sync(x: *mut PsimExchange) -> c_int;
     pub fn psim_exchange_last_list(x: *mut PsimExchange, out_host: *mut PsimAttractor) -> c_int;
     pub fn psim_exchange_world(x: *const PsimExchange) -> c_int;

@@ -22,13 +22,15 @@ from psim_testlib import psim  # noqa: E402
 par = importlib.import_module("particle-simulation-3d_amd.parallel")
 
 
-def one_rank_steps_equal_the_oracle(steps):
+def one_rank_steps_equal_the_oracle(steps, pacing="device", switch_every=0):
     n = 300_007
     params = T.bench_params(gravity=0.5, is_mouse_dragging=0, color_mode=2)
     runner = par.NativeMultiAttractorRunner(n, 0, 1, 0, params, psim.exchange_unique_id(),
-                                            force=60.0, radius=30.0)
+                                            force=60.0, radius=30.0, pacing=pacing)
     try:
-        for _ in range(steps):
+        for t in range(steps):
+            if switch_every and t % switch_every == 0:   # the pacing may change between steps
+                runner.exchange.set_pacing((t // switch_every) % 2)
             runner.step()
         runner.finish()
         got = runner.sim.download_aos()
@@ -111,10 +113,21 @@ def case_host_time_of_a_step_hides_behind_the_kernel():
         for _ in range(steps):
             runner.sim.update_multi(params, table)
         kernel = runner.sim.timer_stop() / steps * 1e3
+        runner.exchange.set_pacing(psim.EXCHANGE_HOST_PACED)
+        for _ in range(30):
+            runner.step()
+        runner.finish()
+        runner.sim.timer_start()
+        for _ in range(steps):
+            runner.step()
+        host_paced = runner.sim.timer_stop() / steps * 1e3
+        runner.finish()
     finally:
         runner.close()
-    print(f"exchanged step {exchanged:.1f} us, the same kernel from a host list {kernel:.1f} us")
+    print(f"exchanged step {exchanged:.1f} us (host-paced {host_paced:.1f} us), "
+          f"the same kernel from a host list {kernel:.1f} us")
     assert exchanged < 1.3 * kernel + 8.0
+    assert host_paced < 1.3 * kernel + 8.0
 
 
 
@@ -132,6 +145,22 @@ def case_one_rank_steps_equal_the_oracle_7():
 
 def case_one_rank_steps_equal_the_oracle_40():
     one_rank_steps_equal_the_oracle(40)              # the ring of 16 lists goes round
+
+
+def case_host_paced_steps_equal_the_oracle_40():
+    one_rank_steps_equal_the_oracle(40, pacing="host")
+
+
+def case_pacing_switched_every_5_steps_equals_the_oracle():
+    one_rank_steps_equal_the_oracle(37, switch_every=5)
+
+
+def case_unknown_pacing_is_rejected():
+    with psim.HipParticleSimulation.new_shard(1000, 0, 1000, psim.GEN_UNIFORM) as sim:
+        with psim.HipAttractorExchange(sim, psim.exchange_unique_id(), 0, 1) as ex:
+            with pytest.raises(psim.PsimError) as e:
+                ex.set_pacing(2)
+            assert e.value.code == 1
 
 
 CASES = sorted(name for name in globals() if name.startswith("case_"))

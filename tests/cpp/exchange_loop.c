@@ -12,6 +12,7 @@
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 #include "psim.h"
@@ -44,8 +45,8 @@ static psim_attractor attractor_at(int rank, int t)
 
 int main(int argc, char **argv)
 {
-    if (argc != 7) {
-        fprintf(stderr, "usage: %s rank world device particles steps id_file\n", argv[0]);
+    if (argc != 7 && argc != 8) {
+        fprintf(stderr, "usage: %s rank world device particles steps id_file [host|device]\n", argv[0]);
         return 2;
     }
     const int rank = atoi(argv[1]), world = atoi(argv[2]), device = atoi(argv[3]);
@@ -57,6 +58,8 @@ int main(int argc, char **argv)
     CHECK(psim_create_shard(&h, n, (uint64_t)rank * n, (uint64_t)world * n, PSIM_GEN_UNIFORM, device));
     CHECK(psim_exchange_rendezvous_file(argv[6], rank, id, 60000));
     CHECK(psim_exchange_create(&x, h, id, rank, world));
+    if (argc == 8 && strcmp(argv[7], "host") == 0)
+        CHECK(psim_exchange_set_pacing(x, PSIM_EXCHANGE_HOST_PACED));
 
     psim_sim_params p = {0.016f, 0.25f, 0u, 5.0f, 10.0f, 0u, 0.99f, 50.0f, {0.0f, 0.0f, 0.0f}, 0u};
     double host_us = 0.0;

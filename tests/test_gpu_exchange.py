@@ -24,12 +24,15 @@ WORKER = os.path.join(T.ROOT, "tests", "_exchange_worker.py")
 CASES = [
     "case_errors",
     "case_file_rendezvous_and_a_second_communicator",
+    "case_host_paced_steps_equal_the_oracle_40",
     "case_host_time_of_a_step_hides_behind_the_kernel",
     "case_one_rank_equals_the_single_attractor_update",
     "case_one_rank_steps_equal_the_oracle_1",
     "case_one_rank_steps_equal_the_oracle_2",
     "case_one_rank_steps_equal_the_oracle_40",
     "case_one_rank_steps_equal_the_oracle_7",
+    "case_pacing_switched_every_5_steps_equals_the_oracle",
+    "case_unknown_pacing_is_rejected",
 ]
 
 
@@ -79,8 +82,8 @@ def test_plain_c_host_of_the_exchange(tmp_path):
     print(f"C host: {host_us:.1f} us of host time, {device_us:.1f} us of device time per step")
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world):
+@pytest.mark.parametrize("world,pacing", [(2, "device"), (3, "device"), (3, "host")])
+def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world, pacing):
     """The exchange's logic for a world larger than one -- every rank's place in the receive
     lists, the ring, the list length the kernel gets, shards of one global array, ranks that
     really wait for the rendezvous file -- with `world` C host processes sharing GPU 0.  RCCL
@@ -93,7 +96,7 @@ def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world):
     n, steps = 50_003, 20                                # 40 steps in all: the ring goes round
     env = dict(os.environ, PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"))
     procs = [subprocess.Popen([os.path.join(cpp_dir, "exchange_loop"), str(r), str(world), "0",
-                               str(n), str(steps), str(tmp_path / "id")], env=env,
+                               str(n), str(steps), str(tmp_path / "id"), pacing], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in reversed(range(world))]            # rank 0 last: the others wait for its file
     outs = {}
