@@ -24,8 +24,6 @@ struct psim_group {
 
 namespace {
 
-// For every shard that overlaps [first, first + n): call fn(shard, first_in_shard, count,
-// offset_in_request).
 // Calls fn(k) for k = 0 .. n-1 on up to 16 host threads (k, k + threads, ... on one thread),
 // so that the shards' synchronous entry points -- generators, record transfers, checksums,
 // checkpoint I/O -- run on all devices at once instead of device after device.  Returns the
@@ -63,7 +61,9 @@ int for_each_concurrently(size_t n, Fn fn)
         return psim_fail(PSIM_ERR_NOMEM, "host allocation failed");
     }
     for (size_t k = 0; k < n; ++k)
-        if (status[k] != PSIM_OK) return psim_fail(status[k], "%s", message[k].c_str());
+        if (status[k] != PSIM_OK)
+            return psim_fail(status[k], "%s",
+                             message[k].empty() ? "host allocation failed" : message[k].c_str());
     return PSIM_OK;
 }
 
