@@ -261,7 +261,7 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
     w, d, k, bad, hp = (float(v) for v in t.tolist())
     return {
         "workload": f"{n} particles per GPU, {world} moving attractors, psim_exchange_step "
-                    f"(RCCL all-gather of 32 B per rank, double-buffered) x {steps} steps",
+                    f"(RCCL all-gather of 32 B per rank into a ring of receive lists) x {steps} steps",
         "lists_match_closed_form": bad == 0.0,
         "us_per_step_wall": w,
         "us_per_step_device": d,

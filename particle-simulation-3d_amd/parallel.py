@@ -5,10 +5,12 @@ pairwise term), so the array is cut into contiguous index ranges and every rank 
 its own range.  With the reference's single attractor the 48-byte SimParams is
 replicated by the host and NO communication happens.  Only the multi-attractor
 extension (one moving attractor owned by each rank; the reference has exactly one)
-exchanges data: a 32-byte record per rank per step, all-gathered with
-torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in CPU tests).
-The exchange is latency-bound (256 B on 8 ranks), so it runs on its own stream into a
-double-buffered receive array and overlaps the previous step's kernel.
+exchanges data: a 32-byte record per rank per step, all-gathered over RCCL (xGMI between
+the GPUs) -- by the library's own exchange (NativeMultiAttractorRunner over psim_exchange_*:
+no torch in the data path) or, as first built, with torch.distributed (MultiAttractorRunner:
+backend "nccl" = RCCL on the GPUs, "gloo" in CPU tests).  The exchange is latency-bound
+(256 B on 8 ranks), so it runs on its own stream into rotating receive buffers and overlaps
+the previous step's kernel.
 """
 from __future__ import annotations
 
