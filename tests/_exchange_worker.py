@@ -155,6 +155,28 @@ def case_pacing_switched_every_5_steps_equals_the_oracle():
     one_rank_steps_equal_the_oracle(37, switch_every=5)
 
 
+def case_three_thousand_small_steps_reuse_the_ring_correctly():
+    """Small kernels, so the host runs far ahead of the device and every reuse of a receive
+    list has to wait for its last reader; the pacing changes every 500 steps."""
+    n, steps = 20_011, 3000
+    params = T.bench_params(gravity=0.5, is_mouse_dragging=0)
+    runner = par.NativeMultiAttractorRunner(n, 0, 1, 0, params, psim.exchange_unique_id(),
+                                            force=60.0, radius=30.0)
+    try:
+        for t in range(steps):
+            if t % 500 == 0:
+                runner.exchange.set_pacing((t // 500) % 2)
+            runner.step()
+        runner.finish()
+        got = runner.sim.download_aos()
+    finally:
+        runner.close()
+    want = T.oracle_gen_uniform_aos(0, n)
+    for t in range(steps):
+        want = T.oracle_update_aos(want, params, 1, par.attractors_at(t, 1, force=60.0, radius=30.0))
+    T.assert_particles_equal(got, want, f"{steps} exchanged steps")
+
+
 def case_unknown_pacing_is_rejected():
     with psim.HipParticleSimulation.new_shard(1000, 0, 1000, psim.GEN_UNIFORM) as sim:
         with psim.HipAttractorExchange(sim, psim.exchange_unique_id(), 0, 1) as ex:

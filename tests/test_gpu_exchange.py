@@ -32,6 +32,7 @@ CASES = [
     "case_one_rank_steps_equal_the_oracle_40",
     "case_one_rank_steps_equal_the_oracle_7",
     "case_pacing_switched_every_5_steps_equals_the_oracle",
+    "case_three_thousand_small_steps_reuse_the_ring_correctly",
     "case_unknown_pacing_is_rejected",
 ]
 
