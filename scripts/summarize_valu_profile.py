@@ -73,7 +73,12 @@ def main():
                 "Issue floor: a SIMD issues a 64-lane vector instruction over 2 cycles, a transcendental "
                 "one (`v_rcp/v_rsq/v_sqrt`: the cores of the correctly rounded divide and square root) over "
                 "8; 1024 SIMDs.  `of issue peak` = floor cycles / cycles the launch took (`GRBM_GUI_ACTIVE` "
-                "/ 8 XCDs).  For comparison the last column prices the same launch against HBM.\n\n")
+                "/ 8 XCDs).  For comparison the last column prices the same launch against HBM.  The floor "
+                "is a lower bound of the cost: measured one kind at a time (`scripts/exp_valu_issue.hip`, "
+                "`profiles/tuning/r02_valu_issue_costs.log`), compares, selects, the `v_div_*` helpers, "
+                "data-parallel primitives and packed fp32 forms take two issue slots each and `v_rcp / "
+                "v_sqrt` 3.5; the fused batch kernel's code averages 1.55 slots per instruction, so its "
+                "0.59 here is 0.8-0.9 of what the vector unit can issue of that mix.\n\n")
         f.write("| operation | launch ms | particle-updates/s | VALU instr / particle-step | of them transcendental | "
                 "clock GHz | issue-floor cycles | cycles taken | **of issue peak** | waves / SIMD | "
                 "wave time stalled on issue | wave time parked (waitcnt) | of 8 TB/s (48 B/particle/launch) |\n")
