@@ -334,10 +334,12 @@ def main():
 
     if workload == "multi":
         if args.exchange == "native":
-            if rehearsal:
-                raise SystemExit("RCCL cannot put two ranks on one GPU: no rehearsal of the exchange")
+            if rehearsal and world > 1 and not os.environ.get("PSIM_RCCL_LIBRARY"):
+                raise SystemExit("RCCL cannot put two ranks on one GPU: a rehearsal of the exchange "
+                                 "needs a stand-in named by PSIM_RCCL_LIBRARY")
             if world > 1:
-                ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8, device="cuda")
+                ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8,
+                                    device="cpu" if rehearsal else "cuda")
                 if rank == 0:
                     ident.copy_(torch.frombuffer(bytearray(psim.exchange_unique_id()),
                                                  dtype=torch.uint8))

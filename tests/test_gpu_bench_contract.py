@@ -184,3 +184,32 @@ def test_multi_gpu_exchange_check_rehearsal():
     assert check["lists_match_closed_form"] is True
     assert check["us_per_step_device"] > 0 and check["us_per_step_kernel_only"] > 0
     assert out["n_gpus"] == 2 and out["value"] > 0
+
+
+def test_config_5_two_rank_rehearsal():
+    """bench.py --config 5 as the driver launches it on several GPUs -- every rank steps its
+    shard through psim_exchange_step, the communicator id travelling over the process group --
+    rehearsed with two ranks on one GPU (gloo between the ranks, the shared-memory test double
+    under the exchange)."""
+    cpp_dir = os.path.join(T.ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp_dir, "libfake_rccl.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, PSIM_BENCH_REHEARSAL="1",
+               PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for pacing in ("host", "device"):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                            "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29549", os.path.join(T.ROOT, "bench.py"),
+                            "--gpus", "2", "--config", "5", "--steps", "40", "--warmup", "5",
+                            "--particles", "500000", "--pacing", pacing],
+                           capture_output=True, text=True, timeout=280, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout[:1000]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 5
+        assert out["config"]["total_particles"] == 1_000_000
+        assert f"{pacing}-paced" in out["config"]["sharding"]
+        assert "2 moving attractors" in out["config"]["workload"]
+        assert abs(out["value"] - 1_000_000 * 40 / (out["ms_per_step"] * 40e-3)) / out["value"] < 1e-6
