@@ -8,6 +8,8 @@ every rank holds its own shard (weak scaling: the per-GPU count is fixed; `--sca
 the total is fixed and divided).  The single-attractor path needs no communication, so
 torch.distributed is used only for the barriers and the max-over-ranks of the timing.
 
+  --config 1   100 k particles, single attractor: the reference's own CPU-runnable case (on the
+               GPU a launch-bound 3 us step; the CPU restatement is timed beside it)
   --config 2   10 M particles, single attractor (fits the Infinity Cache: cache-assisted)
   --config 3   100 M particles per GPU, single attractor            (headline, default)
   --config 4   1 B particles over 8 GPUs = 125 M per GPU, single attractor, no collective
@@ -43,6 +45,9 @@ KERNEL_SOURCES = ("psim_kernels.hip", "psim_kernels.h", "psim_threshold.h", "Mak
 # name, particles per GPU as written (the 8-GPU configurations divided by 8), total when the
 # particle count is held fixed instead (--scaling strong), workload
 CONFIGS = {
+    1: ("configs[0]: 100k particles, single point attractor (the reference's CPU-runnable case, "
+        "here on the GPU with the CPU restatement timed beside it; launch-bound at this size)",
+        100_000, 100_000, "single"),
     2: ("configs[1]: 10M particles, single attractor", 10_000_000, 10_000_000, "single"),
     3: ("configs[2]: 100M particles, single attractor", 100_000_000, 100_000_000, "single"),
     4: ("configs[3]: 1B particles over 8 GPUs (125M per GPU), single attractor, no collective",

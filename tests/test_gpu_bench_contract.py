@@ -102,20 +102,21 @@ def test_multi_workload_line(exchange):
     assert out["value"] > 0 and out["roofline"]["traffic"] is None
 
 
-@pytest.mark.parametrize("config,per_gpu,workload", [(2, 10_000_000, "single"),
+@pytest.mark.parametrize("config,per_gpu,workload", [(1, 100_000, "single"),
+                                                      (2, 10_000_000, "single"),
                                                       (3, 100_000_000, "single"),
                                                       (4, 125_000_000, "single"),
                                                       (5, 6_250_000, "multi")])
 def test_baseline_config_presets(config, per_gpu, workload):
     """--config N names the baseline's configuration N as written.  Run at the preset's own
-    size when that takes a moment (2, 5), at a reduced size otherwise; the preset sizes are
+    size when that takes a moment (1, 2, 5), at a reduced size otherwise; the preset sizes are
     checked against the table either way."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(T.ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert bench.CONFIGS[config][1] == per_gpu and bench.CONFIGS[config][3] == workload
-    full_size = config in (2, 5)
+    full_size = config in (1, 2, 5)
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
