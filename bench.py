@@ -485,8 +485,11 @@ def main():
             check = {"error": f"{type(e).__name__}: {e}"}
         guard.cancel()
         emit(check)
-        if "error" in check:                         # the other ranks may be stuck in a collective:
-            os._exit(0)                              # no barrier, no tidy shutdown
+        # The ranks left the check together (its last step is a reduction over all of them), or
+        # some of them never will: either way each ends here on its own -- no further barrier
+        # that a rank which has gone could hold up, no tear-down of two communicators.
+        sys.stderr.flush()
+        os._exit(0)
     else:
         emit()
 
