@@ -71,16 +71,10 @@ def parse_args():
     ap.add_argument("--workload", choices=["single", "multi"], default=None,
                     help="single: one attractor, no communication; multi: one moving attractor "
                          "per rank, all-gathered every step (default: what --config says)")
-    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
-                    help="multi workload: the library's own RCCL exchange (psim_exchange_*) or "
-                         "torch.distributed's all_gather_into_tensor")
     ap.add_argument("--pacing", choices=["host", "device"], default="host",
-                    help="multi workload with --exchange native: who waits for a step's "
-                         "all-gather, the calling thread (kernels then run back to back) or "
-                         "the kernel's stream (see psim_exchange_set_pacing)")
-    ap.add_argument("--lookahead", type=int, default=1,
-                    help="multi workload with --exchange torch: steps of attractor state "
-                         "exchanged per all-gather (1 = one collective per step)")
+                    help="multi workload: who waits for a step's all-gather, the calling thread "
+                         "(kernels then run back to back) or the kernel's stream (see "
+                         "psim_exchange_set_pacing)")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="particles stepped by the CPU baseline (default: the GPU's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -305,8 +299,7 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the process group is used even for one rank
-    distributed = world > 1 or (workload == "multi" and args.exchange == "torch") \
-        or "RANK" in os.environ
+    distributed = world > 1 or "RANK" in os.environ
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -338,25 +331,21 @@ def main():
                             max_dist_for_color=50.0, mouse_position=(0.0, 0.0, 48.0))
 
     if workload == "multi":
-        if args.exchange == "native":
-            if rehearsal and world > 1 and not os.environ.get("PSIM_RCCL_LIBRARY"):
-                raise SystemExit("RCCL cannot put two ranks on one GPU: a rehearsal of the exchange "
-                                 "needs a stand-in named by PSIM_RCCL_LIBRARY")
-            if world > 1:
-                ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8,
-                                    device="cpu" if rehearsal else "cuda")
-                if rank == 0:
-                    ident.copy_(torch.frombuffer(bytearray(psim.exchange_unique_id()),
-                                                 dtype=torch.uint8))
-                dist.broadcast(ident, 0)
-                unique_id = ident.cpu().numpy().tobytes()
-            else:
-                unique_id = psim.exchange_unique_id()
-            runner = par.NativeMultiAttractorRunner(n, rank, world, local_rank, params, unique_id,
-                                                    first=first, total=total, pacing=args.pacing)
+        if rehearsal and world > 1 and not os.environ.get("PSIM_RCCL_LIBRARY"):
+            raise SystemExit("RCCL cannot put two ranks on one GPU: a rehearsal of the exchange "
+                             "needs a stand-in named by PSIM_RCCL_LIBRARY")
+        if world > 1:
+            ident = torch.zeros(psim.EXCHANGE_ID_BYTES, dtype=torch.uint8,
+                                device="cpu" if rehearsal else "cuda")
+            if rank == 0:
+                ident.copy_(torch.frombuffer(bytearray(psim.exchange_unique_id()),
+                                             dtype=torch.uint8))
+            dist.broadcast(ident, 0)
+            unique_id = ident.cpu().numpy().tobytes()
         else:
-            runner = par.MultiAttractorRunner(n, rank, world, local_rank, params,
-                                              lookahead=args.lookahead, first=first, total=total)
+            unique_id = psim.exchange_unique_id()
+        runner = par.NativeMultiAttractorRunner(n, rank, world, local_rank, params, unique_id,
+                                                first=first, total=total, pacing=args.pacing)
         step, finish, sim = runner.step, runner.finish, runner.sim
     else:
         runner = None
@@ -410,10 +399,8 @@ def main():
             kernel = "psim::update_kernel<colour 0, single attractor>"
             what = "single attractor, SoA fp32, dt 0.016, damping 0.99, attractor (0,0,48) r 10 f 5"
         else:
-            every = "every step" if args.lookahead == 1 or args.exchange == "native" else \
-                f"every {args.lookahead} steps ({args.lookahead} x 32 B per rank)"
-            sharding = (f"contiguous index ranges x{world}, all-gather of 32 B per rank {every} "
-                        f"({'psim_exchange_step: RCCL behind the C ABI, ' + args.pacing + '-paced' if args.exchange == 'native' else 'torch.distributed'})")
+            sharding = (f"contiguous index ranges x{world}, all-gather of 32 B per rank every step "
+                        f"(psim_exchange_step: RCCL behind the C ABI, {args.pacing}-paced)")
             kernel = ("psim::update_kernel<colour 0, attractor list staged in LDS> "
                       "(launch_ms here also holds the waits for the per-step all-gather)")
             what = f"{world} moving attractors (one per rank, r 10 f 5) all-gathered over RCCL"

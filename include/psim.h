@@ -548,6 +548,20 @@ int psim_exchange_last_list(psim_exchange *x, psim_attractor *out_host);
 int psim_exchange_world(const psim_exchange *x);
 int psim_exchange_rank(const psim_exchange *x);
 
+/* ---- debugging -------------------------------------------------------------- */
+
+/* Overrides one of the measured launch-shape choices of this process, for kernel experiments
+ * and for tests that must force a shape the library would not pick at their size.  The
+ * reference hard-codes its one dispatch shape (src/simulation/compute.rs:142-143) and has no
+ * counterpart.  `name` is one of "nt", "reserve_lds", "max_blocks", "skew_bytes" (copied when a
+ * handle is created), "queue_from", "aos_stream", "aos_reserve", "aos_block", "aos_ppl",
+ * "checksum_blocks", "exchange_event_fences" (read at each launch / when an exchange is
+ * created); value -1 restores the automatic choice.  This call -- or a process started with
+ * PSIM_EXPERIMENT=1, which reads PSIM_<NAME> variables once -- is the ONLY way to change a
+ * launch shape: no other environment variable is consulted.  Results never depend on the
+ * shape, only speed does.  Not thread-safe against launches in flight on other threads. */
+int psim_debug_set_tuning(const char *name, int value);
+
 /* ---- errors --------------------------------------------------------------- */
 
 /* Text of the most recent failure on the calling thread ("" if none). */

@@ -199,6 +199,7 @@ ABI = {
     "psim_device_count": (c_int, []),
     "psim_timer_start": (c_int, [_P]),
     "psim_timer_stop": (c_int, [_P, POINTER(c_float)]),
+    "psim_debug_set_tuning": (c_int, [c_char_p, c_int]),
     "psim_last_error": (c_char_p, []),
     "psim_version": (c_char_p, []),
 }
@@ -591,7 +592,7 @@ class HipAttractorExchange:
     """`psim_exchange_*`: the multi-attractor step of a set sharded over one process per GPU.
     Every rank owns one attractor; step() all-gathers the ranks' records with RCCL on a stream
     of its own (into a ring of receive lists, overlapping the previous steps' kernels) and applies them all
-    to the particles of `sim`.  No torch involved."""
+    to the particles of `sim`; the data path is the library's own."""
 
     def __init__(self, sim, unique_id, rank, world):
         self._lib = load_library()
@@ -725,6 +726,12 @@ def read_checkpoint_records(path, first=0, n=None):
         return np.empty(0, dtype=PARTICLE_DTYPE)
     return np.memmap(path, dtype=PARTICLE_DTYPE, mode="r",
                      offset=CHECKPOINT_HEADER_BYTES + first * PARTICLE_DTYPE.itemsize, shape=(n,))
+
+
+def debug_set_tuning(name, value):
+    """Overrides a launch-shape choice of this process (psim_debug_set_tuning: experiments and
+    shape-forcing tests); value -1 restores the automatic choice."""
+    _check(load_library().psim_debug_set_tuning(name.encode(), int(value)))
 
 
 def device_count():

@@ -22,6 +22,7 @@
 #include "psim_checkpoint_file.h"
 #include "psim_hostgen.h"
 #include "psim_kernels.h"
+#include "psim_tuning.h"
 
 static_assert(sizeof(psim_sim_params) == 48, "SimParams is 48 bytes (mod.rs:52-67)");
 static_assert(offsetof(psim_sim_params, color_mode) == 8, "layout");
@@ -79,27 +80,20 @@ constexpr uint32_t kCapacityQuantum = 1024;    // particles; keeps every array 4
 constexpr uint32_t kListSlots = 4;             // host attractor lists in flight per handle
 constexpr uint64_t kScratchBytes = 256 + kListSlots * PSIM_MAX_ATTRACTORS * sizeof(psim_attractor) + 3840;
 
-int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    return atoi(v);
-}
-
-// Optional overrides of the measured launch shape (experiments only): each is
-// read from the environment when a handle is created; -1 / unset = automatic.
+// Overrides of the measured launch shape (psim_tuning.h: experiments and shape-forcing
+// tests only), copied when a handle is created; -1 = automatic.
 struct TuningOverrides {
-    int nontemporal = -1;   // PSIM_NT           0 plain | 1 streaming | 2 cache-resident accesses
-    int reserve_lds = -1;   // PSIM_RESERVE_LDS  bytes of LDS reserved per workgroup
-    int max_blocks = -1;    // PSIM_MAX_BLOCKS   grid cap (0 = one pass)
+    int nontemporal = -1;   // 0 plain | 1 streaming | 2 cache-resident accesses
+    int reserve_lds = -1;   // bytes of LDS reserved per workgroup
+    int max_blocks = -1;    // grid cap (0 = one pass)
 };
 
 TuningOverrides read_overrides()
 {
     TuningOverrides o;
-    o.nontemporal = env_int("PSIM_NT", -1);
-    o.reserve_lds = env_int("PSIM_RESERVE_LDS", -1);
-    o.max_blocks = env_int("PSIM_MAX_BLOCKS", -1);
+    o.nontemporal = psim::knob(psim::KNOB_NT);
+    o.reserve_lds = psim::knob(psim::KNOB_RESERVE_LDS);
+    o.max_blocks = psim::knob(psim::KNOB_MAX_BLOCKS);
     return o;
 }
 
@@ -180,7 +174,8 @@ uint32_t round_capacity(uint32_t n)
 int allocate(psim_handle *h, uint32_t capacity)
 {
     const uint64_t cap = capacity;
-    const uint64_t skew = (uint64_t)env_int("PSIM_SKEW_BYTES", 0) & ~255ull;
+    const int skew_knob = psim::knob(psim::KNOB_SKEW_BYTES);
+    const uint64_t skew = (uint64_t)(skew_knob < 0 ? 0 : skew_knob) & ~255ull;
     const uint64_t f32_bytes = cap * 4 + skew;
     const uint64_t total = 6 * f32_bytes + cap * 16 * 2 + cap * 8 + kScratchBytes;
     void *slab = nullptr;
@@ -430,7 +425,7 @@ int create_impl(psim_handle **out, uint32_t count, uint64_t global_first, uint64
     HIP_TRY(hipSetDevice(device_id));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !env_int("PSIM_ALLOW_ANY_ARCH", 0))
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(PSIM_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
                     device_id, prop.gcnArchName);
 
@@ -665,7 +660,7 @@ PSIM_API int psim_update_soa(float *px, float *py, float *pz, float *vx, float *
     const bool vec = aligned16(px) && aligned16(py) && aligned16(pz) && aligned16(vx) &&
                      aligned16(vy) && aligned16(vz) && (!colours || aligned16(color));
     if (vec) {
-        static const TuningOverrides overrides = read_overrides();   // read once per process
+        const TuningOverrides overrides = read_overrides();
         psim::LaunchTuning t = tuning_for(count, 1, overrides);
         // The sc1 / nt sc1 stores write partial 128-byte lines through to memory; arrays
         // that are 16-byte but not line-aligned are faster with plain accesses (100 M
@@ -1210,7 +1205,7 @@ PSIM_API int psim_checksum(psim_handle *h, uint64_t out[6])
     if (!out) return fail(PSIM_ERR_INVALID, "null output");
     // One 256-thread workgroup per CU reads fastest (100 M particles, GB/s of the 24 B read:
     // 128 workgroups 4.2 k, 256 6.8 k, 512 6.4 k, 4096 5.8 k).
-    int blocks = env_int("PSIM_CHECKSUM_BLOCKS", h->num_cus);
+    int blocks = psim::knob(psim::KNOB_CHECKSUM_BLOCKS);
     if (blocks < 1) blocks = h->num_cus > 0 ? h->num_cus : 256;
     HIP_TRY(psim::launch_checksum(h->soa, h->count, h->checksum_dev, (uint32_t)blocks, h->stream));
     HIP_TRY(hipMemcpyAsync(out, h->checksum_dev, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost,

@@ -48,6 +48,7 @@
 #include <rccl/rccl.h>
 
 #include "psim.h"
+#include "psim_tuning.h"
 
 #define PSIM_API extern "C" __attribute__((visibility("default")))
 
@@ -251,8 +252,8 @@ int create_impl(psim_exchange *x, const uint8_t *id)
     // kernel_done only orders the next writer of a list behind its last reader: no data
     // passes through it, so it needs no system-scope fence.  gathered hands the collective's
     // output (written by other GPUs' kernels too) to the update kernel and keeps the default.
-    const char *knob = getenv("PSIM_EXCHANGE_EVENT_FENCES");     // experiments only
-    const int fences = knob && *knob ? atoi(knob) : 1;
+    const int fence_knob = psim::knob(psim::KNOB_EXCHANGE_EVENT_FENCES);
+    const int fences = fence_knob < 0 ? 1 : fence_knob;
     for (hipEvent_t &e : x->gathered)
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming |
                                         ((fences & 2) ? hipEventDisableSystemFence : 0)));

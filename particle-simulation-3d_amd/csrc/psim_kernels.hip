@@ -19,6 +19,7 @@
 
 #include "psim_kernels.h"
 #include "psim_threshold.h"
+#include "psim_tuning.h"
 
 #pragma clang fp contract(off)
 
@@ -906,16 +907,11 @@ static UpdateLaunch pick_cm(uint32_t color_mode, const LaunchTuning &t)
     }
 }
 
-// Experiments only: PSIM_QUEUE_FROM overrides the list length from which the queued form
-// is used (0 = never).
+// The host list length from which the queued form is used (KNOB_QUEUE_FROM: 0 = never).
 static uint32_t queue_from()
 {
-    static const uint32_t v = [] {
-        const char *e = getenv("PSIM_QUEUE_FROM");
-        const int x = e && *e ? atoi(e) : 2;
-        return x <= 0 ? 0xFFFFFFFFu : (uint32_t)x;
-    }();
-    return v;
+    const int x = knob(KNOB_QUEUE_FROM);
+    return x < 0 ? 2u : (x == 0 ? 0xFFFFFFFFu : (uint32_t)x);
 }
 
 // force as launch_update() takes it (0 none, 1 SimParams, 2 device list, 3 host list).
@@ -1428,29 +1424,23 @@ __global__ void __launch_bounds__(64) export_aos_wide_kernel(SoaPtrs s, uint32_t
 // 6.25 -> 6.77 k).  Plain accesses win while the SoA and AoS sides together fit the
 // 256 MiB Infinity Cache (2 M particles: 7.0-7.1 k against 6.2 / 5.8 k streaming), streaming
 // from 2.5 M particles on (6.2 / 5.9 k against 5.9 / 5.8 k).
-// Experiments only: PSIM_AOS_RESERVE overrides the LDS reservation of both transposes,
-// PSIM_AOS_BLOCK (64 or 256) their workgroup size, PSIM_AOS_STREAM (0 / 1) the access form.
-static int aos_env(const char *name)
-{
-    const char *e = getenv(name);
-    return e && *e ? atoi(e) : -1;
-}
-
+// Overrides (psim_tuning.h): KNOB_AOS_RESERVE the LDS reservation of both transposes,
+// KNOB_AOS_BLOCK (64 or 256) their workgroup size, KNOB_AOS_STREAM (0 / 1) the access form.
 static bool aos_streaming(uint32_t n)
 {
-    const int v = aos_env("PSIM_AOS_STREAM");          // read per launch: tests switch it
+    const int v = knob(KNOB_AOS_STREAM);
     return v >= 0 ? v != 0 : (uint64_t)n * 128u > 288000000ull;
 }
 
 static uint32_t aos_reserve(uint32_t automatic)
 {
-    const int v = aos_env("PSIM_AOS_RESERVE");          // read per launch: tests switch it
+    const int v = knob(KNOB_AOS_RESERVE);
     return v >= 0 ? (uint32_t)v : automatic;
 }
 
 static bool aos_single_wave(bool automatic)
 {
-    const int v = aos_env("PSIM_AOS_BLOCK");          // read per launch: tests switch it
+    const int v = knob(KNOB_AOS_BLOCK);
     return v == 64 ? true : (v == (int)PSIM_BLOCK ? false : automatic);
 }
 
@@ -1478,10 +1468,10 @@ static void launch_transpose(const SoaPtrs &s, uint32_t first, uint32_t n,
     }
 }
 
-// Experiments: PSIM_AOS_PPL = 1 (one particle per lane, the kernels above), 2 or 4.
+// KNOB_AOS_PPL = 1 (one particle per lane, the kernels above), 2 or 4.
 static int aos_ppl(int automatic)
 {
-    const int v = aos_env("PSIM_AOS_PPL");          // read per launch: tests switch it
+    const int v = knob(KNOB_AOS_PPL);
     return v == 1 || v == 2 || v == 4 ? v : automatic;
 }
 

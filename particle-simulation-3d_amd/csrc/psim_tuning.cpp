@@ -1,0 +1,75 @@
+// psim_tuning.cpp -- the table behind psim_tuning.h and psim_debug_set_tuning().
+#include "psim_tuning.h"
+
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
+#include "psim.h"
+
+#define PSIM_API extern "C" __attribute__((visibility("default")))
+
+// The error sink of the library (psim_api.hip).
+int psim_fail(int code, const char *fmt, ...);
+
+namespace psim {
+namespace {
+
+const char *const kNames[KNOB_COUNT] = {
+    "nt", "reserve_lds", "max_blocks", "skew_bytes", "queue_from", "aos_stream",
+    "aos_reserve", "aos_block", "aos_ppl", "checksum_blocks", "exchange_event_fences",
+};
+
+std::atomic<int> g_value[KNOB_COUNT];
+std::once_flag g_once;
+
+// PSIM_EXPERIMENT=1 is the one switch that lets the environment reach the launch shapes: the
+// sweep scripts under scripts/ run the library in child processes and set it beside the
+// PSIM_<NAME> variables.  Without it no environment variable changes what is launched.
+void initialise()
+{
+    for (auto &v : g_value) v.store(-1, std::memory_order_relaxed);
+    const char *on = getenv("PSIM_EXPERIMENT");
+    if (!on || strcmp(on, "1") != 0) return;
+    for (int k = 0; k < KNOB_COUNT; ++k) {
+        char var[64] = "PSIM_";
+        size_t at = strlen(var);
+        for (const char *c = kNames[k]; *c && at + 1 < sizeof(var); ++c) var[at++] = (char)toupper(*c);
+        var[at] = 0;
+        const char *e = getenv(var);
+        if (e && *e) g_value[k].store(atoi(e), std::memory_order_relaxed);
+    }
+}
+
+}  // namespace
+
+int knob(Knob k)
+{
+    std::call_once(g_once, initialise);
+    return g_value[k].load(std::memory_order_relaxed);
+}
+
+bool set_knob(const char *name, int value)
+{
+    std::call_once(g_once, initialise);
+    for (int k = 0; k < KNOB_COUNT; ++k)
+        if (strcmp(name, kNames[k]) == 0) {
+            g_value[k].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+            return true;
+        }
+    return false;
+}
+
+}  // namespace psim
+
+PSIM_API int psim_debug_set_tuning(const char *name, int value)
+{
+    if (!name) return psim_fail(PSIM_ERR_INVALID, "null name");
+    if (!psim::set_knob(name, value))
+        return psim_fail(PSIM_ERR_INVALID, "unknown tuning override \"%s\"", name);
+    return PSIM_OK;
+}

@@ -203,6 +203,7 @@ extern "C" {
     pub fn psim_exchange_last_list(x: *mut PsimExchange, out_host: *mut PsimAttractor) -> c_int;
     pub fn psim_exchange_world(x: *const PsimExchange) -> c_int;
     pub fn psim_exchange_rank(x: *const PsimExchange) -> c_int;
+    pub fn psim_debug_set_tuning(name: *const c_char, value: c_int) -> c_int;
     pub fn psim_last_error() -> *const c_char;
     pub fn psim_version() -> *const c_char;
 }

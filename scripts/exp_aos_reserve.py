@@ -38,7 +38,7 @@ if __name__ == "__main__":
     else:
         n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
         for r in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("", "0", "6144", "10240", "15872", "24064", "36864", "65024")):
-            env = dict(os.environ)
+            env = dict(os.environ, PSIM_EXPERIMENT="1")   # the switch that lets PSIM_* reach a launch
             env.pop("PSIM_AOS_RESERVE", None)
             if r:
                 env["PSIM_AOS_RESERVE"] = r

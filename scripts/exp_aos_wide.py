@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""AoS export / import with 1, 2 or 4 particles per lane (PSIM_AOS_PPL) by extra LDS
-reservation (PSIM_AOS_RESERVE, bytes of dynamic LDS on top of what the kernel declares: fewer
+"""AoS export / import with 1, 2 or 4 particles per lane (override aos_ppl) by extra LDS
+reservation (override aos_reserve, bytes of dynamic LDS on top of what the kernel declares: fewer
 resident waves per CU).  Prints GB/s of the 128 B per particle moved; every variant's result
 is first compared with the one-particle-per-lane kernels' (all 64 bytes of every record)."""
 import importlib
@@ -33,8 +33,8 @@ def main():
     buf = scratch.get_particle_buffer().color
     scratch.set_stream(sim.get_stream())
     sim.update(psim.SimParams(color_mode=1, is_mouse_dragging=1, mouse_radius=40.0))
-    os.environ["PSIM_AOS_PPL"] = "1"
-    os.environ.pop("PSIM_AOS_RESERVE", None)
+    psim.debug_set_tuning("aos_ppl", 1)
+    psim.debug_set_tuning("aos_reserve", -1)
     sim.export_aos_device(buf)
     sim.sync()
     want = sim.checksum()
@@ -47,20 +47,17 @@ def main():
         sweep = tuple((int(a.split(":")[0]), tuple(a.split(":")[1].split(","))) for a in sys.argv[2:])
     for ppl, reserves in sweep:
         for r in reserves:
-            os.environ["PSIM_AOS_PPL"] = str(ppl)
-            if r:
-                os.environ["PSIM_AOS_RESERVE"] = r
-            else:
-                os.environ.pop("PSIM_AOS_RESERVE", None)
+            psim.debug_set_tuning("aos_ppl", ppl)
+            psim.debug_set_tuning("aos_reserve", int(r) if r else -1)
             # correctness: records out with this variant, state wiped, records back in
             sim.export_aos_device(buf)
             sim.reset(psim.GEN_HOLLOW if n <= 20_000_000 else psim.GEN_UNIFORM)
             sim.import_aos_device(buf)
             sim.sync()
             ok = sim.checksum() == want
-            os.environ["PSIM_AOS_PPL"] = "1"
+            psim.debug_set_tuning("aos_ppl", 1)
             ok = ok and sim.download_aos(0, probe.stop).tobytes() == want_head.tobytes()
-            os.environ["PSIM_AOS_PPL"] = str(ppl)
+            psim.debug_set_tuning("aos_ppl", ppl)
             ex = rate(sim, lambda: sim.export_aos_device(buf), n)
             im = rate(sim, lambda: sim.import_aos_device(buf), n)
             print(f"particles per lane {ppl}  extra LDS {r or 'auto':>6}: export {ex:7.1f} GB/s  "

@@ -5,7 +5,7 @@ n = 100_000_000
 sim = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
 ref = sim.checksum()
 for b in (64, 128, 192, 256, 320, 384, 512, 768):
-    os.environ["PSIM_CHECKSUM_BLOCKS"] = str(b)
+    psim.debug_set_tuning("checksum_blocks", b)
     assert sim.checksum() == ref
     t0 = time.perf_counter()
     for _ in range(10): sim.checksum()

@@ -49,7 +49,7 @@ if __name__ == "__main__":
     else:
         settings = sys.argv[4].split(";") if len(sys.argv) > 4 else [""]
         for setting in settings:
-            env = dict(os.environ)
+            env = dict(os.environ, PSIM_EXPERIMENT="1")   # the switch that lets PSIM_* reach a launch
             for pair in filter(None, (x.strip() for x in setting.split(","))):
                 k, v = pair.split("=")
                 env[k] = v

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the update kernel under different launch shapes (PSIM_* environment knobs are
+"""Times the update kernel under different launch shapes (psim_debug_set_tuning overrides are
 read when a handle is created).  Variants run interleaved, several rounds, in one
 process; prints median / best achieved GB/s (48 B per particle-update)."""
 import argparse
@@ -35,9 +35,9 @@ def main():
                                       args.lds.split(",")))
     sims = {}
     for v in variants:
-        os.environ["PSIM_NT"] = v[0]
-        os.environ["PSIM_MAX_BLOCKS"], os.environ["PSIM_SKEW_BYTES"] = v[2], v[3]
-        os.environ["PSIM_RESERVE_LDS"] = v[4]
+        for name, value in (("nt", v[0]), ("max_blocks", v[2]), ("skew_bytes", v[3]),
+                            ("reserve_lds", v[4])):
+            psim.debug_set_tuning(name, int(value))      # copied when the handle is created
         sims[v] = psim.HipParticleSimulation.new(n, psim.GEN_UNIFORM)
         for _ in range(3):
             sims[v].update(params)

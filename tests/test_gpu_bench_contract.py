@@ -93,12 +93,13 @@ def test_one_rank_under_the_launcher_uses_rccl():
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
 
 
-@pytest.mark.parametrize("exchange", ["native", "torch"])
-def test_multi_workload_line(exchange):
-    out = run_bench("--workload", "multi", "--exchange", exchange, "--no-cpu-baseline")
+@pytest.mark.parametrize("pacing", ["host", "device"])
+def test_multi_workload_line(pacing):
+    out = run_bench("--workload", "multi", "--pacing", pacing, "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and "cpu_baseline" not in out
     assert "all-gather" in out["config"]["sharding"]
-    assert ("psim_exchange_step" in out["config"]["sharding"]) == (exchange == "native")
+    assert "psim_exchange_step" in out["config"]["sharding"]
+    assert f"{pacing}-paced" in out["config"]["sharding"]
     assert out["value"] > 0 and out["roofline"]["traffic"] is None
 
 

@@ -1,6 +1,8 @@
-"""GPU test of the sharded multi-attractor runner: per-step all-gather over RCCL on its
-own stream, double-buffered, feeding the LDS-staged multi-attractor kernel.  One rank
-here (a single-GPU box); the world_size > 1 host logic is covered on CPU over gloo."""
+"""GPU cross-check of the multi-attractor kernel fed by a SECOND, independent exchange: the
+runner of tests/torch_exchange.py (test scaffolding: all-gather through torch.distributed's
+RCCL backend on its own stream, double-buffered).  The product's exchange is psim_exchange_*
+(tests/test_gpu_exchange.py); both must leave the particles the oracle leaves.  One rank here
+(a single-GPU box); the world_size > 1 host logic is covered on CPU over gloo."""
 import os
 import socket
 import subprocess

@@ -145,12 +145,11 @@ def test_aos_round_trip_keeps_all_64_bytes(n):
 @pytest.mark.parametrize("ppl", ["1", "2", "4"])
 def test_transposes_with_several_particles_per_lane(ppl, stream):
     """The AoS transposes exist with 1, 2 and 4 particles per lane, plain and streaming; the
-    library picks by size (PSIM_AOS_PPL / PSIM_AOS_STREAM force a form, read per launch).  Every
-    form must move all 64 bytes of every record, whole tiles, ragged tails and ranges that
-    start inside a tile or off a 4-particle boundary alike."""
-    import os
-    saved = {k: os.environ.get(k) for k in ("PSIM_AOS_PPL", "PSIM_AOS_STREAM")}
-    os.environ["PSIM_AOS_PPL"], os.environ["PSIM_AOS_STREAM"] = ppl, stream
+    library picks by size (psim_debug_set_tuning forces a form).  Every form must move all
+    64 bytes of every record, whole tiles, ragged tails and ranges that start inside a tile or
+    off a 4-particle boundary alike."""
+    psim.debug_set_tuning("aos_ppl", int(ppl))
+    psim.debug_set_tuning("aos_stream", int(stream))
     try:
         n = 70_001                                       # 273 tiles of 256 and a tail of 113
         p = random_particles(n, 3)
@@ -176,11 +175,8 @@ def test_transposes_with_several_particles_per_lane(ppl, stream):
                 assert sim.download_aos(8, n - 8).tobytes() == p[8:].tobytes()
             assert view.count == n
     finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        psim.debug_set_tuning("aos_ppl", -1)
+        psim.debug_set_tuning("aos_stream", -1)
 
 
 def test_soa_upload_download():
