@@ -557,9 +557,10 @@ int psim_exchange_rank(const psim_exchange *x);
  * handle is created), "queue_from", "aos_stream", "aos_reserve", "aos_block", "aos_ppl",
  * "checksum_blocks", "exchange_event_fences" (read at each launch / when an exchange is
  * created); value -1 restores the automatic choice.  This call -- or a process started with
- * PSIM_EXPERIMENT=1, which reads PSIM_<NAME> variables once -- is the ONLY way to change a
- * launch shape: no other environment variable is consulted.  Results never depend on the
- * shape, only speed does.  Not thread-safe against launches in flight on other threads. */
+ * the variable PSIM_EXPERIMENT set to "1", which reads PSIM_<NAME> variables once -- is the
+ * ONLY way to change a launch shape: no other environment variable is consulted.  Results
+ * never depend on the shape, only speed does.  Not thread-safe against launches in flight on
+ * other threads. */
 int psim_debug_set_tuning(const char *name, int value);
 
 /* ---- errors --------------------------------------------------------------- */
