@@ -164,15 +164,21 @@ def load_traffic(particles, identity):
     return info
 
 
-EXCHANGE_CHECK_SECONDS = 120.0
+# The extra multi-GPU run after the headline: the exchange itself gives up on a collective
+# that does not complete (psim_exchange_set_timeout), the watchdog is the net under that.
+# (The variable shortens the watchdog for the test that rehearses an abandoned check.)
+EXCHANGE_CHECK_SECONDS = float(os.environ.get("PSIM_BENCH_EXCHANGE_CHECK_SECONDS", "120"))
+EXCHANGE_TIMEOUT_MS = 30_000
+EXIT_EXCHANGE_CHECK_FAILED = 3
 
 
 class Watchdog:
     """Gives up on the code it guards after `seconds`, or when the launcher sends SIGTERM
     (a sibling rank died): calls `give_up(reason)` on a thread of its own -- the main thread may
-    be blocked inside a collective that will never finish -- and ends the process."""
+    be blocked inside a collective that will never finish -- and ends the process with
+    `status`, which is not 0: what was guarded did not complete."""
 
-    def __init__(self, seconds, give_up):
+    def __init__(self, seconds, give_up, status):
         import select
         import signal
         import threading
@@ -188,7 +194,7 @@ class Watchdog:
             if self._stop_r in ready:
                 return
             give_up("terminated by the launcher" if ready else f"no result after {seconds:.0f} s")
-            os._exit(0)
+            os._exit(status)
 
         self._thread = threading.Thread(target=watch, daemon=True)
         self._thread.start()
@@ -214,7 +220,8 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
         ident.copy_(torch.frombuffer(bytearray(psim.exchange_unique_id()), dtype=torch.uint8))
     dist.broadcast(ident, 0)
     runner = par.NativeMultiAttractorRunner(n, rank, world, local_rank, params,
-                                            bytes(ident.cpu().numpy().tobytes()))
+                                            bytes(ident.cpu().numpy().tobytes()),
+                                            timeout_ms=EXCHANGE_TIMEOUT_MS)
     for _ in range(warmup):
         runner.step()
     runner.finish()
@@ -463,20 +470,32 @@ def main():
         # an error, a hang, a rank killed by the launcher -- the line still goes out.
         sim.close()
         sim = None
-        guard = Watchdog(EXCHANGE_CHECK_SECONDS,
-                         lambda why: emit({"error": f"exchange check abandoned: {why}"}))
+        def abandoned(why):
+            print(f"rank {rank}: exchange check abandoned: {why}", file=sys.stderr, flush=True)
+            emit({"error": f"exchange check abandoned: {why}"})
+
+        guard = Watchdog(EXCHANGE_CHECK_SECONDS, abandoned, EXIT_EXCHANGE_CHECK_FAILED)
+        failed = False
         try:
             check = exchange_check(psim, par, torch, dist, rank, world, local_rank, params,
                                    rehearsal=rehearsal)
         except Exception as e:                       # noqa: BLE001 -- reported in the line
             check = {"error": f"{type(e).__name__}: {e}"}
+            failed = True
+            print(f"rank {rank}: exchange check failed: {check['error']}", file=sys.stderr,
+                  flush=True)
         guard.cancel()
+        if not failed and not check.get("lists_match_closed_form", False):
+            failed = True
+            print(f"rank {rank}: exchange check: the gathered lists differ from the closed-form "
+                  "paths", file=sys.stderr, flush=True)
         emit(check)
         # The ranks left the check together (its last step is a reduction over all of them), or
         # some of them never will: either way each ends here on its own -- no further barrier
-        # that a rank which has gone could hold up, no tear-down of two communicators.
+        # that a rank which has gone could hold up, no tear-down of two communicators.  The
+        # headline line is out in every case; the exit status says whether the check completed.
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(EXIT_EXCHANGE_CHECK_FAILED if failed else 0)
     else:
         emit()
 

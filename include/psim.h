@@ -193,14 +193,19 @@ int psim_update_multi_host(psim_handle *h, const psim_sim_params *params,
 
 /* psim_update_multi_host for callers that cannot allocate: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
- * The call allocates nothing, on the host or the device, and uses no copy engine: the list
- * (at most PSIM_MAX_ATTRACTORS records; more is PSIM_ERR_INVALID) is written by small kernels
+ * The call allocates nothing, on the host or the device, and moves the list without a copy
+ * engine: it (at most PSIM_MAX_ATTRACTORS records; more is PSIM_ERR_INVALID) is written by small kernels
  * that carry it in their arguments into a static device array of the library -- 2 KiB that
  * every GPU the library runs on holds until the process ends -- and the update kernel stages
  * it from there into LDS.  The result is that of psim_update_multi_host, bit for bit.  All
  * handles on one GPU share that array: calls on one stream follow each other safely, calls
- * that overlap on different streams of one GPU race for it.  Asynchronous; the host list is
- * copied before returning. */
+ * that overlap on different streams of one GPU race for it -- and so do two graphs holding
+ * such calls when they are captured or replayed at the same time on one GPU.  Under
+ * PSIM_COLOR_RESET a step in a mode other than 1 / 2 that follows changed colours also
+ * enqueues one device-to-device copy of count x 16 bytes (the colour reset of psim_update),
+ * and whether it does is decided when the call is made, i.e. at capture: capture a graph in
+ * the colour state it will be replayed in.  Asynchronous; the host list is copied before
+ * returning. */
 int psim_update_multi_host_noalloc(psim_handle *h, const psim_sim_params *params,
                                    const psim_attractor *attractors_host, uint32_t n_attractors);
 
@@ -350,9 +355,10 @@ typedef struct psim_checkpoint_header {
 /* Writes the handle's particles to `path` (created when missing), streaming them through
  * page-locked memory while the file writes proceed.  A plain handle invalidates the header
  * first and writes it last, so an interrupted write leaves no valid file, and truncates the
- * file to its exact size.  A shard writes only its own records, at their place in the
- * whole-set file, and never the header (`step` is ignored); the shard that owns the last
- * particle sets the file size.  Shards -- in one process or many -- follow
+ * file to its exact size.  A shard invalidates the header too, then writes only its own
+ * records, at their place in the whole-set file, and never a valid header (`step` is
+ * ignored); the shard that owns the last particle sets the file size.  Shards -- in one
+ * process or many -- follow
  *     psim_checkpoint_begin(path)            once, before any shard writes
  *     psim_checkpoint_write(shard, path, 0)  every shard, any order, also at the same time
  *     psim_checkpoint_commit(shard, path, step)   once, after every shard has returned
@@ -366,8 +372,10 @@ int psim_checkpoint_begin(const char *path);
 
 /* Writes the header of the whole set `h` belongs to (any of its shards, or a plain handle)
  * after checking that the file has exactly the size of that set; fails with PSIM_ERR_IO
- * when it has not, i.e. when the shard owning the last particle has not written.  Touches
- * no device memory. */
+ * when it has not, i.e. when the shard owning the last particle has not written.  The size
+ * is a sanity check only -- a file that existed before already has it: that EVERY shard has
+ * written is what the caller's barrier before this call guarantees.  Touches no device
+ * memory. */
 int psim_checkpoint_commit(const psim_handle *h, const char *path, uint64_t step);
 
 /* Restores the handle's particles from `path`: the header's particle_count must equal the
@@ -538,6 +546,24 @@ enum {
 };
 int psim_exchange_set_pacing(psim_exchange *x, int pacing);
 
+/* A way out of a collective that will never finish.  By default (0) the exchange waits for
+ * ever, like RCCL itself: when a rank dies, the others hang in their next wait.  With a timeout
+ * every host-side wait of the exchange -- the gather of a host-paced step, psim_exchange_sync,
+ * psim_exchange_last_list, psim_exchange_destroy -- polls instead of blocking, asks the
+ * communicator for asynchronous errors (ncclCommGetAsyncError) while it does, and after
+ * timeout_ms without completion aborts the communicator (ncclCommAbort) and returns
+ * PSIM_ERR_COMM; a device-paced step additionally waits for the gather enqueued 16 steps
+ * earlier, so the host never runs more than the ring ahead of a collective that hangs.  After
+ * PSIM_ERR_COMM from any call of this section -- a timeout, or a step that failed half-way for
+ * any reason -- the ranks are out of step: the exchange is unusable (every further call
+ * returns PSIM_ERR_COMM; destroy it, and tear the other ranks down too) and the particles are
+ * defined only as far as the steps that had been applied before (a host-paced step that times
+ * out has not enqueued its kernel; a device-paced run may have applied kernels to lists the
+ * aborted collective never filled: restore from a checkpoint).  The reference's only failure
+ * policy is to abort the process (`panic = "abort"`, Cargo.toml:49); a run sharded over
+ * processes needs to be able to report instead.  Each rank sets its own timeout. */
+int psim_exchange_set_timeout(psim_exchange *x, uint32_t timeout_ms);
+
 /* Waits for everything the exchange and its handle have enqueued. */
 int psim_exchange_sync(psim_exchange *x);
 
@@ -555,8 +581,8 @@ int psim_exchange_rank(const psim_exchange *x);
  * reference hard-codes its one dispatch shape (src/simulation/compute.rs:142-143) and has no
  * counterpart.  `name` is one of "nt", "reserve_lds", "max_blocks", "skew_bytes" (copied when a
  * handle is created), "queue_from", "aos_stream", "aos_reserve", "aos_block", "aos_ppl",
- * "checksum_blocks", "exchange_event_fences" (read at each launch / when an exchange is
- * created); value -1 restores the automatic choice.  This call -- or a process started with
+ * "checksum_blocks", "exchange_event_fences", "exchange_comm_priority" (read at each launch /
+ * when an exchange is created); value -1 restores the automatic choice.  This call -- or a process started with
  * the variable PSIM_EXPERIMENT set to "1", which reads PSIM_<NAME> variables once -- is the
  * ONLY way to change a launch shape: no other environment variable is consulted.  Results
  * never depend on the shape, only speed does.  Not thread-safe against launches in flight on

@@ -282,6 +282,8 @@ public:
     }
     // PSIM_EXCHANGE_DEVICE_PACED (default) or PSIM_EXCHANGE_HOST_PACED
     void set_pacing(int pacing) { check(psim_exchange_set_pacing(x_, pacing)); }
+    // 0 (default): wait for ever; otherwise host-side waits give up after that long
+    void set_timeout(uint32_t timeout_ms) { check(psim_exchange_set_timeout(x_, timeout_ms)); }
     void sync() { check(psim_exchange_sync(x_)); }
     std::vector<Attractor> last_list()
     {

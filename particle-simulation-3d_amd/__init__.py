@@ -189,6 +189,7 @@ ABI = {
     "psim_exchange_destroy": (None, [_P]),
     "psim_exchange_step": (c_int, [_P, POINTER(SimParams), _P]),
     "psim_exchange_set_pacing": (c_int, [_P, c_int]),
+    "psim_exchange_set_timeout": (c_int, [_P, c_uint32]),
     "psim_exchange_sync": (c_int, [_P]),
     "psim_exchange_last_list": (c_int, [_P, _P]),
     "psim_exchange_world": (c_int, [_P]),
@@ -619,6 +620,11 @@ class HipAttractorExchange:
     def set_pacing(self, pacing):
         """EXCHANGE_DEVICE_PACED (default) or EXCHANGE_HOST_PACED: see include/psim.h."""
         _check(self._lib.psim_exchange_set_pacing(self._x, int(pacing)))
+
+    def set_timeout(self, timeout_ms):
+        """0 (default): wait for ever.  Otherwise every host-side wait gives the exchange up
+        after `timeout_ms` (PsimError with code 6 = PSIM_ERR_COMM): see include/psim.h."""
+        _check(self._lib.psim_exchange_set_timeout(self._x, int(timeout_ms)))
 
     def sync(self):
         _check(self._lib.psim_exchange_sync(self._x))

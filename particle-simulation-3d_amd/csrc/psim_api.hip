@@ -1239,11 +1239,11 @@ PSIM_API int psim_checkpoint_write(psim_handle *h, const char *path, uint64_t st
     const uint64_t first = h->global_first;
     psim_checkpoint_header hdr;
     memset(&hdr, 0, sizeof(hdr));
-    int rc = PSIM_OK;
-    if (!shard) {                                   // no valid header while the records change
-        rc = write_all(f.fd, &hdr, sizeof(hdr), 0, path);
-        if (rc != PSIM_OK) return rc;
-    }
+    // No valid header while records change.  A shard does this too (it is idempotent, and all
+    // shards do it before the barrier that precedes the commit): a caller that forgot
+    // psim_checkpoint_begin cannot leave an older, valid header over half-rewritten records.
+    int rc = write_all(f.fd, &hdr, sizeof(hdr), 0, path);
+    if (rc != PSIM_OK) return rc;
     const int fd = f.fd;
     rc = download_aos_through_slots(
         h, 0, h->count, [fd, first, path](const psim_particle *slot, uint64_t off, uint64_t m) {

@@ -69,6 +69,10 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
                               hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // The way out of a collective that will never finish (a rank died).  Optional: a library
+    // without them still exchanges, it just cannot give up.
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
     char why[256] = "";
 };
 
@@ -100,6 +104,9 @@ void load_rccl()
     PSIM_RCCL_SYMBOL(AllGather, "ncclAllGather")
     PSIM_RCCL_SYMBOL(GetErrorString, "ncclGetErrorString")
 #undef PSIM_RCCL_SYMBOL
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
+    r.CommGetAsyncError =
+        reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(r.lib, "ncclCommGetAsyncError"));
 }
 
 // Null (with the reason recorded) when RCCL is not usable.
@@ -145,11 +152,101 @@ struct psim_exchange {
     hipEvent_t kernel_done[2] = {nullptr, nullptr};   // per half: its last kernel has finished
     uint64_t t = 0;                                   // steps taken
     bool host_paced = false;                          // see psim_exchange_set_pacing()
+    uint32_t timeout_ms = 0;                          // 0 = wait for ever, see psim_exchange_set_timeout()
+    bool broken = false;                              // a step failed or timed out: unusable
+    char why_broken[200] = "";
 };
 
 namespace {
 constexpr uint32_t kHalf = 8, kRing = 2 * kHalf;
 static_assert(sizeof(psim_exchange::gathered) / sizeof(hipEvent_t) == kRing, "one event per list");
+
+int64_t now_ms()
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (int64_t)t.tv_sec * 1000 + t.tv_nsec / 1000000;
+}
+
+// The exchange is finished: the ranks are no longer in step, so nothing collective may follow.
+// The communicator is aborted, which lets RCCL's kernels on the device leave their waits, so
+// that the streams drain and the process can tear down; the lists they leave are garbage.
+int give_up(psim_exchange *x, const char *why)
+{
+    if (!x->broken) {
+        x->broken = true;
+        snprintf(x->why_broken, sizeof(x->why_broken), "%s", why);
+        if (x->comm && g_rccl.CommAbort) {
+            (void)g_rccl.CommAbort(x->comm);          // frees the communicator
+            x->comm = nullptr;
+        }
+    }
+    return psim_fail(PSIM_ERR_COMM, "rank %d of %d: %s; the exchange cannot be used any more",
+                     x->rank, x->world, x->why_broken);
+}
+
+// What the communicator reports about collectives already enqueued (a peer that went away,
+// a network error): false when it reports a failure.
+bool comm_healthy(const psim_exchange *x, char *why, size_t why_bytes)
+{
+    if (!x->comm || !g_rccl.CommGetAsyncError) return true;
+    ncclResult_t state = ncclSuccess;
+    const ncclResult_t asked = g_rccl.CommGetAsyncError(x->comm, &state);
+    if (asked == ncclSuccess && (state == ncclSuccess || state == ncclInProgress)) return true;
+    snprintf(why, why_bytes, "the communicator reports \"%s\"",
+             g_rccl.GetErrorString(asked != ncclSuccess ? asked : state));
+    return false;
+}
+
+// Waits until `ready()` (a hipEventQuery / hipStreamQuery) stops saying hipErrorNotReady.
+// Without a timeout this is never called: the plain blocking calls are used.  With one, the
+// calling thread polls -- the readiness, and what the communicator says about itself -- until
+// the deadline, and gives the exchange up when it passes.
+template <typename Ready>
+int wait_with_deadline(psim_exchange *x, Ready ready, const char *what)
+{
+    const int64_t start = now_ms(), deadline = start + (int64_t)x->timeout_ms;
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t e = ready();
+        if (e == hipSuccess) return PSIM_OK;
+        char why[160];
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            snprintf(why, sizeof(why), "%s failed: %s", what, hipGetErrorString(e));
+            return give_up(x, why);
+        }
+        (void)hipGetLastError();                      // NotReady is sticky in the runtime's last error
+        if ((spins & 63u) == 63u && !comm_healthy(x, why, sizeof(why))) return give_up(x, why);
+        if (now_ms() >= deadline) {
+            snprintf(why, sizeof(why), "%s did not finish within %u ms (a rank has gone?)", what,
+                     x->timeout_ms);
+            return give_up(x, why);
+        }
+        if (spins > 2000) {                           // a gather takes tens of microseconds: spin
+            const struct timespec nap = {0, 50000};   // first, then stop burning the core
+            (void)nanosleep(&nap, nullptr);
+        }
+    }
+}
+
+int wait_event(psim_exchange *x, hipEvent_t e, const char *what)
+{
+    if (x->timeout_ms == 0) {
+        HIP_TRY(hipEventSynchronize(e));
+        return PSIM_OK;
+    }
+    return wait_with_deadline(x, [e] { return hipEventQuery(e); }, what);
+}
+
+int wait_stream(psim_exchange *x, hipStream_t s, const char *what)
+{
+    if (x->timeout_ms == 0) {
+        HIP_TRY(hipStreamSynchronize(s));
+        return PSIM_OK;
+    }
+    return wait_with_deadline(x, [s] { return hipStreamQuery(s); }, what);
+}
+
 }  // namespace
 
 // ---- rendezvous ---------------------------------------------------------------------
@@ -219,10 +316,14 @@ PSIM_API void psim_exchange_destroy(psim_exchange *x)
 {
     if (!x) return;
     (void)hipSetDevice(x->device);
+    // With a timeout the communication stream gets that long to drain; a collective still stuck
+    // then is aborted, or the wait below would never return.
+    if (x->timeout_ms && !x->broken && x->comm_stream)
+        (void)wait_stream(x, x->comm_stream, "the communication stream");
     // Kernels on the handle's stream may still read the lists.  The handle is the caller's and
     // may already be gone, so it is not touched here: the whole device is waited for instead.
     (void)hipDeviceSynchronize();
-    if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
+    if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);   // null once aborted
     for (hipEvent_t e : x->gathered)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : x->kernel_done)
@@ -239,11 +340,16 @@ int create_impl(psim_exchange *x, const uint8_t *id)
     const Rccl *r = rccl();
     if (!r) return PSIM_ERR_COMM;
     HIP_TRY(hipSetDevice(x->device));
-    // communication ahead of compute when both are ready: the gather is tiny and the next
-    // kernel waits for it
+    // The communication stream runs at the priority of the handle's stream.  The highest
+    // priority buys nothing measurable (one rank, 6.25 M particles: 47.3 / 44.6 us per step
+    // device- / host-paced either way), and a high-priority queue that waits -- at the start of
+    // each half of the ring -- for kernels of a normal-priority queue is a priority inversion:
+    // with several rank processes sharing one GPU, one rank's waiting communication queue kept
+    // another rank's kernels from being scheduled, and the ranks waited for each other for ever.
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&x->comm_stream, hipStreamNonBlocking, greatest));
+    const int priority = psim::knob(psim::KNOB_EXCHANGE_COMM_PRIORITY) == 1 ? greatest : 0;
+    HIP_TRY(hipStreamCreateWithPriority(&x->comm_stream, hipStreamNonBlocking, priority));
     void *buffers = nullptr;
     const size_t bytes = (size_t)kRing * (size_t)x->world * sizeof(psim_attractor);
     HIP_TRY(hipMalloc(&buffers, bytes));
@@ -297,16 +403,22 @@ PSIM_API int psim_exchange_create(psim_exchange **out, psim_handle *h,
 
 // ---- the step ----------------------------------------------------------------------------
 
-PSIM_API int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
-                                const psim_attractor *mine)
+namespace {
+
+int step_impl(psim_exchange *x, const psim_sim_params *params, const psim_attractor *mine)
 {
-    if (!x) return psim_fail(PSIM_ERR_INVALID, "null exchange");
-    if (!params || !mine) return psim_fail(PSIM_ERR_INVALID, "null argument");
     const Rccl *r = &g_rccl;                         // loaded: the exchange exists
     HIP_TRY(hipSetDevice(x->device));
     const uint32_t slot = (uint32_t)(x->t % kRing), half = slot / kHalf;
     hipStream_t compute = static_cast<hipStream_t>(psim_get_stream(x->h));
     psim_attractor *list = x->ring + (size_t)slot * (size_t)x->world;
+    // With a timeout the host never runs more than a ring ahead of the collectives: the gather
+    // that used this list 16 steps ago must have finished, or the exchange is given up here --
+    // which is how a device-paced run notices that a rank has gone.
+    if (x->timeout_ms && x->t >= kRing) {
+        const int rc = wait_event(x, x->gathered[slot], "an all-gather enqueued 16 steps ago");
+        if (rc != PSIM_OK) return rc;
+    }
     if (slot % kHalf == 0 && x->t >= kRing)          // the kernels that read this half are done
         HIP_TRY(hipStreamWaitEvent(x->comm_stream, x->kernel_done[half], 0));
     int rc = psim_store_attractor(list + x->rank, mine, x->comm_stream);
@@ -317,7 +429,8 @@ PSIM_API int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
     if (x->host_paced) {
         // The HOST waits for the gather (which runs under the previous step's kernel), so the
         // kernel goes into its queue with nothing in front of it but the previous kernel.
-        HIP_TRY(hipEventSynchronize(x->gathered[slot]));
+        rc = wait_event(x, x->gathered[slot], "the all-gather of this step");
+        if (rc != PSIM_OK) return rc;
     } else {
         HIP_TRY(hipStreamWaitEvent(compute, x->gathered[slot], 0));
     }
@@ -326,6 +439,25 @@ PSIM_API int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
     if (slot % kHalf == kHalf - 1) HIP_TRY(hipEventRecord(x->kernel_done[half], compute));
     ++x->t;
     return PSIM_OK;
+}
+
+}  // namespace
+
+PSIM_API int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
+                                const psim_attractor *mine)
+{
+    if (!x) return psim_fail(PSIM_ERR_INVALID, "null exchange");
+    if (!params || !mine) return psim_fail(PSIM_ERR_INVALID, "null argument");
+    if (x->broken) return give_up(x, x->why_broken);
+    const int rc = step_impl(x, params, mine);
+    // A step that failed half-way leaves this rank out of step with the others (its collective
+    // may or may not have been enqueued): whatever the reason, the exchange is finished.
+    if (rc != PSIM_OK && !x->broken) {
+        char why[200];
+        snprintf(why, sizeof(why), "a step failed (%.150s)", psim_last_error());
+        (void)give_up(x, why);                       // the error text now names both
+    }
+    return rc;
 }
 
 PSIM_API int psim_exchange_set_pacing(psim_exchange *x, int pacing)
@@ -337,12 +469,22 @@ PSIM_API int psim_exchange_set_pacing(psim_exchange *x, int pacing)
     return PSIM_OK;
 }
 
+PSIM_API int psim_exchange_set_timeout(psim_exchange *x, uint32_t timeout_ms)
+{
+    if (!x) return psim_fail(PSIM_ERR_INVALID, "null exchange");
+    x->timeout_ms = timeout_ms;
+    return PSIM_OK;
+}
+
 PSIM_API int psim_exchange_sync(psim_exchange *x)
 {
     if (!x) return psim_fail(PSIM_ERR_INVALID, "null exchange");
     HIP_TRY(hipSetDevice(x->device));
-    HIP_TRY(hipStreamSynchronize(x->comm_stream));
-    return psim_sync(x->h);
+    if (x->broken) return give_up(x, x->why_broken);
+    int rc = wait_stream(x, x->comm_stream, "the communication stream");
+    if (rc != PSIM_OK) return rc;
+    if (x->timeout_ms == 0) return psim_sync(x->h);
+    return wait_stream(x, static_cast<hipStream_t>(psim_get_stream(x->h)), "the handle's stream");
 }
 
 PSIM_API int psim_exchange_last_list(psim_exchange *x, psim_attractor *out_host)

@@ -22,6 +22,7 @@ namespace {
 const char *const kNames[KNOB_COUNT] = {
     "nt", "reserve_lds", "max_blocks", "skew_bytes", "queue_from", "aos_stream",
     "aos_reserve", "aos_block", "aos_ppl", "checksum_blocks", "exchange_event_fences",
+    "exchange_comm_priority",
 };
 
 std::atomic<int> g_value[KNOB_COUNT];

@@ -22,6 +22,7 @@ enum Knob : int {
     KNOB_AOS_PPL,              // transposes: 1, 2 or 4 particles per lane
     KNOB_CHECKSUM_BLOCKS,      // checksum: workgroups
     KNOB_EXCHANGE_EVENT_FENCES,// exchange: bit 0 kernel_done, bit 1 gathered without system fence
+    KNOB_EXCHANGE_COMM_PRIORITY,// exchange: 1 = communication stream at the highest priority (automatic: normal)
     KNOB_COUNT
 };
 

@@ -68,10 +68,11 @@ class NativeMultiAttractorRunner:
     made it (HipParticleSimulation-side helpers: exchange_unique_id, exchange_rendezvous_file).
     Attractor `rank` follows the closed-form path of attractor_at().  `pacing` "host" makes
     the calling thread wait for each gather so that the kernels run back to back (see
-    psim_exchange_set_pacing in include/psim.h)."""
+    psim_exchange_set_pacing in include/psim.h); `timeout_ms` > 0 bounds every wait of the
+    exchange (psim_exchange_set_timeout)."""
 
     def __init__(self, particles_per_rank, rank, world, local_rank, params, unique_id,
-                 force=5.0, radius=10.0, first=None, total=None, pacing="device"):
+                 force=5.0, radius=10.0, first=None, total=None, pacing="device", timeout_ms=0):
         from . import HipAttractorExchange, EXCHANGE_DEVICE_PACED, EXCHANGE_HOST_PACED
         self.rank, self.world, self.params = rank, world, params
         self.force, self.radius = force, radius
@@ -83,6 +84,8 @@ class NativeMultiAttractorRunner:
         self.exchange = HipAttractorExchange(self.sim, unique_id, rank, world)
         self.exchange.set_pacing({"device": EXCHANGE_DEVICE_PACED,
                                   "host": EXCHANGE_HOST_PACED}[pacing])
+        if timeout_ms:                 # give up (PsimError, code 6) instead of hanging on a lost rank
+            self.exchange.set_timeout(timeout_ms)
         self.t = 0
         self._path = None          # own attractor records for steps [_path_first, +len)
         self._path_first = 0

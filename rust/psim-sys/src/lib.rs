@@ -199,6 +199,7 @@ extern "C" {
     pub fn psim_exchange_destroy(x: *mut PsimExchange);
     pub fn psim_exchange_step(x: *mut PsimExchange, params: *const PsimSimParams, mine: *const PsimAttractor) -> c_int;
     pub fn psim_exchange_set_pacing(x: *mut PsimExchange, pacing: c_int) -> c_int;
+    pub fn psim_exchange_set_timeout(x: *mut PsimExchange, timeout_ms: u32) -> c_int;
     pub fn psim_exchange_sync(x: *mut PsimExchange) -> c_int;
     pub fn psim_exchange_last_list(x: *mut PsimExchange, out_host: *mut PsimAttractor) -> c_int;
     pub fn psim_exchange_world(x: *const PsimExchange) -> c_int;

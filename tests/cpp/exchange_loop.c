@@ -8,12 +8,21 @@
  * compares with the CPU oracle's.
  *
  * usage: exchange_loop <rank> <world> <device> <particles_per_rank> <steps> <id_file>
+ *                      [host|device] [key=value ...]
+ *   force=F radius=R   every attractor's force and radius (default 40, 25)
+ *   timeout_ms=N       psim_exchange_set_timeout: give up instead of hanging when a rank has gone
+ *   nap_us=N           the host sleeps N microseconds per step (a frame loop with other work)
+ *   die_after=K        this rank leaves the run (exit status 0, nothing torn down) after K steps,
+ *                      as a rank that crashed would
  * prints: host_us_per_step device_us_per_step checksum[6]
+ * exit status: 0 done, 1 a call failed, 2 usage, 3 the exchange gave up (PSIM_ERR_COMM: the
+ * message goes to stderr with the seconds the failing call took)
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "psim.h"
 
@@ -24,19 +33,34 @@ static double now_us(void)
     return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
 }
 
+static psim_handle *g_handle = NULL;
+static psim_exchange *g_exchange = NULL;
+
+/* A failed call ends the program through an orderly tear-down: after PSIM_ERR_COMM the
+ * exchange has aborted its communicator, and destroying it must not hang either. */
 #define CHECK(call)                                                          \
     do {                                                                     \
-        if ((call) != PSIM_OK) {                                             \
-            fprintf(stderr, "%s: %s\n", #call, psim_last_error());           \
-            return 1;                                                        \
+        const double t_call_ = now_us();                                     \
+        const int rc_ = (call);                                              \
+        if (rc_ != PSIM_OK) {                                                \
+            fprintf(stderr, "%s: %s [status %d after %.3f s]\n", #call,      \
+                    psim_last_error(), rc_, (now_us() - t_call_) * 1e-6);    \
+            psim_exchange_destroy(g_exchange);                               \
+            psim_destroy(g_handle);                                          \
+            fprintf(stderr, "torn down\n");                                  \
+            return rc_ == PSIM_ERR_COMM ? 3 : 1;                             \
         }                                                                    \
     } while (0)
 
 /* attractor of `rank` at step t: exactly representable steps, so that a checker in another
  * language reproduces it without rounding questions */
+static float g_force = 40.0f, g_radius = 25.0f;
+
 static psim_attractor attractor_at(int rank, int t)
 {
-    psim_attractor a = {{0.0f, 0.0f, 0.0f}, 40.0f, 25.0f, 1u, {0u, 0u}};
+    psim_attractor a = {{0.0f, 0.0f, 0.0f}, 0.0f, 0.0f, 1u, {0u, 0u}};
+    a.force = g_force;
+    a.radius = g_radius;
     a.position[0] = -40.0f + 10.0f * (float)rank + 0.25f * (float)(t % 64);
     a.position[1] = 30.0f - 0.5f * (float)(t % 32);
     a.position[2] = -20.0f + 5.0f * (float)rank;
@@ -45,9 +69,26 @@ static psim_attractor attractor_at(int rank, int t)
 
 int main(int argc, char **argv)
 {
-    if (argc != 7 && argc != 8) {
-        fprintf(stderr, "usage: %s rank world device particles steps id_file [host|device]\n", argv[0]);
+    if (argc < 7) {
+        fprintf(stderr, "usage: %s rank world device particles steps id_file [host|device] "
+                        "[force=F] [radius=R] [timeout_ms=N] [nap_us=N] [die_after=K]\n", argv[0]);
         return 2;
+    }
+    unsigned timeout_ms = 0;
+    int die_after = -1, host_paced = 0;
+    unsigned nap_us = 0;
+    for (int k = 7; k < argc; ++k) {
+        if (strcmp(argv[k], "host") == 0) host_paced = 1;
+        else if (strcmp(argv[k], "device") == 0) host_paced = 0;
+        else if (sscanf(argv[k], "force=%f", &g_force) == 1) {}
+        else if (sscanf(argv[k], "radius=%f", &g_radius) == 1) {}
+        else if (sscanf(argv[k], "timeout_ms=%u", &timeout_ms) == 1) {}
+        else if (sscanf(argv[k], "die_after=%d", &die_after) == 1) {}
+        else if (sscanf(argv[k], "nap_us=%u", &nap_us) == 1) {}
+        else {
+            fprintf(stderr, "unknown argument %s\n", argv[k]);
+            return 2;
+        }
     }
     const int rank = atoi(argv[1]), world = atoi(argv[2]), device = atoi(argv[3]);
     const uint32_t n = (uint32_t)strtoul(argv[4], NULL, 10);
@@ -56,10 +97,12 @@ int main(int argc, char **argv)
     psim_exchange *x = NULL;
     uint8_t id[PSIM_EXCHANGE_ID_BYTES];
     CHECK(psim_create_shard(&h, n, (uint64_t)rank * n, (uint64_t)world * n, PSIM_GEN_UNIFORM, device));
+    g_handle = h;
     CHECK(psim_exchange_rendezvous_file(argv[6], rank, id, 60000));
     CHECK(psim_exchange_create(&x, h, id, rank, world));
-    if (argc == 8 && strcmp(argv[7], "host") == 0)
-        CHECK(psim_exchange_set_pacing(x, PSIM_EXCHANGE_HOST_PACED));
+    g_exchange = x;
+    if (host_paced) CHECK(psim_exchange_set_pacing(x, PSIM_EXCHANGE_HOST_PACED));
+    if (timeout_ms) CHECK(psim_exchange_set_timeout(x, timeout_ms));
 
     psim_sim_params p = {0.016f, 0.25f, 0u, 5.0f, 10.0f, 0u, 0.99f, 50.0f, {0.0f, 0.0f, 0.0f}, 0u};
     double host_us = 0.0;
@@ -69,8 +112,17 @@ int main(int argc, char **argv)
         if (pass == 1) CHECK(psim_timer_start(h));
         const double t0 = now_us();
         for (int t = 0; t < steps; ++t) {
+            if (pass * steps + t == die_after) {
+                CHECK(psim_sync(h));                /* what was enqueued has run: then gone */
+                fprintf(stderr, "rank %d leaves after %d steps\n", rank, die_after);
+                _exit(0);
+            }
             const psim_attractor mine = attractor_at(rank, pass * steps + t);
             CHECK(psim_exchange_step(x, &p, &mine));
+            if (nap_us) {
+                const struct timespec nap = {nap_us / 1000000u, (long)(nap_us % 1000000u) * 1000L};
+                (void)nanosleep(&nap, NULL);
+            }
         }
         if (pass == 1) {
             host_us = (now_us() - t0) / steps;

@@ -215,3 +215,128 @@ def test_config_5_two_rank_rehearsal():
         assert f"{pacing}-paced" in out["config"]["sharding"]
         assert "2 moving attractors" in out["config"]["workload"]
         assert abs(out["value"] - 1_000_000 * 40 / (out["ms_per_step"] * 40e-3)) / out["value"] < 1e-6
+
+
+# ---- readiness for a multi-GPU node: worlds of 4 and 8 rehearsed on this machine's GPU --------
+
+def launch_ranks(world, *args, port, env_extra=None, timeout=280):
+    """bench.py under torch.distributed.run exactly as the driver launches it, `world` ranks
+    sharing the GPUs that exist (PSIM_BENCH_REHEARSAL: gloo between the ranks, the shared-memory
+    test double under the library's exchange)."""
+    cpp_dir = os.path.join(T.ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp_dir, "libfake_rccl.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, PSIM_BENCH_REHEARSAL="1",
+               PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"), OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(T.ROOT, "bench.py"),
+                        "--gpus", str(world), *args],
+                       capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    return r, lines
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_weak_scaling_line_and_exchange_check_at_four_and_eight_ranks(world):
+    """--config 3 (reduced per-GPU count) as `--gpus 4` / `--gpus 8`: the whole-job value over
+    all ranks, one line from rank 0, and the appended exchange check -- the 50 M-particle
+    configuration's own step, 6.25 M particles on every rank with `world` attractors --
+    delivering the closed-form lists on every rank."""
+    n = 1_000_000
+    r, lines = launch_ranks(world, "--config", "3", "--steps", "5", "--warmup", "2",
+                            "--particles", str(n), port=29551 + world)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[:1000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and "cpu_baseline" not in out
+    assert out["config"]["total_particles"] == world * n
+    assert abs(out["value"] - world * n * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-6
+    assert out["per_rank_ms_per_step"]["max"] * (1 + 1e-9) >= out["ms_per_step"] * 0.5
+    check = out["exchange_check"]
+    assert "error" not in check, check
+    assert check["lists_match_closed_form"] is True
+    assert f"{world} moving attractors" in check["workload"]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_billion_particle_configuration_line_at_four_and_eight_ranks(world):
+    """--config 4 names 125 M particles per GPU; rehearsed at a reduced per-GPU count, every
+    rank a shard at its own offset of the one global array."""
+    n = 2_000_000
+    r, lines = launch_ranks(world, "--config", "4", "--steps", "5", "--warmup", "2",
+                            "--particles", str(n), "--no-exchange-check", port=29561 + world)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert len(lines) == 1 and out["config"]["baseline_config"] == 4 and out["n_gpus"] == world
+    assert out["config"]["total_particles"] == world * n and "exchange_check" not in out
+    assert "no data-path collective" in out["config"]["sharding"]
+
+
+@pytest.mark.parametrize("world,pacing", [(4, "host"), (8, "host"), (8, "device")])
+def test_multi_attractor_configuration_line_at_four_and_eight_ranks(world, pacing):
+    """--config 5 at its own per-GPU size (6.25 M particles) on 4 and 8 ranks: every rank
+    steps its shard through psim_exchange_step."""
+    r, lines = launch_ranks(world, "--config", "5", "--steps", "40", "--warmup", "5",
+                            "--pacing", pacing, port=29571 + world)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[:1000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["config"]["baseline_config"] == 5
+    assert out["config"]["particles_per_gpu"] == 6_250_000
+    assert out["config"]["total_particles"] == world * 6_250_000
+    assert f"{world} moving attractors" in out["config"]["workload"]
+    assert f"{pacing}-paced" in out["config"]["sharding"]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_strong_scaling_line_at_four_and_eight_ranks(world):
+    """--scaling strong: a fixed total that does not divide evenly, over 4 and 8 ranks."""
+    total = 8_000_003
+    r, lines = launch_ranks(world, "--scaling", "strong", "--steps", "5", "--warmup", "2",
+                            "--particles", str(total), "--no-exchange-check", port=29581 + world)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert len(lines) == 1 and out["scaling"] == "strong" and out["n_gpus"] == world
+    assert out["config"]["total_particles"] == total
+    assert abs(out["value"] - total * 5 / (out["ms_per_step"] * 5e-3)) / out["value"] < 1e-6
+
+
+def test_an_abandoned_exchange_check_is_reported_and_fails_the_run():
+    """The check after the headline may hang or fail on a machine where the headline ran: the
+    line must still go out (with the error in it), and the run must NOT report success.  Here
+    the watchdog is given half a second, less than the check needs."""
+    r, lines = launch_ranks(2, "--steps", "5", "--warmup", "2", "--particles", "1000000",
+                            port=29591, env_extra={"PSIM_BENCH_EXCHANGE_CHECK_SECONDS": "0.5"})
+    assert r.returncode != 0, "an abandoned check must not exit with status 0"
+    assert len(lines) == 1, r.stdout[:1000]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == 2          # the headline is intact
+    assert "abandoned" in out["exchange_check"]["error"]
+    assert "exchange check abandoned" in r.stderr           # every rank leaves a trace
+
+
+def test_one_rank_under_the_launcher_measures_what_the_plain_run_measures():
+    """`python bench.py` and the driver's launch line with one rank (process group over RCCL,
+    device barriers) at the headline size: the same workload, and rates within noise."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PSIM_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    args = ["--steps", "40", "--warmup", "10", "--no-cpu-baseline"]
+    plain = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), *args],
+                           capture_output=True, text=True, timeout=280, env=env)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    under = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                            "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                            "--master-port", "29593", os.path.join(T.ROOT, "bench.py"),
+                            "--gpus", "1", *args],
+                           capture_output=True, text=True, timeout=280, env=env)
+    assert under.returncode == 0, under.stderr[-3000:]
+    a = json.loads([ln for ln in plain.stdout.splitlines() if ln.strip().startswith("{")][0])
+    b = json.loads([ln for ln in under.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert a["config"] == b["config"] and a["config"]["particles_per_gpu"] == 100_000_000
+    assert abs(a["value"] - b["value"]) / a["value"] < 0.05, (a["value"], b["value"])
+    assert abs(a["roofline"]["launch_ms"] - b["roofline"]["launch_ms"]) / a["roofline"]["launch_ms"] < 0.05
+    print(f"plain {a['value']:.4g} updates/s, under the launcher {b['value']:.4g}")

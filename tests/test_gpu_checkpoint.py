@@ -166,3 +166,27 @@ def test_an_interrupted_sharded_write_leaves_no_valid_file(tmp_path):
         assert psim.checkpoint_info(fresh)["step"] == 2
         want = np.concatenate([a.download_aos(), b.download_aos()])
     assert psim.read_checkpoint_records(fresh).tobytes() == want.tobytes()
+
+
+def test_a_shard_that_writes_without_begin_still_invalidates_the_old_header(tmp_path):
+    """A caller that forgets psim_checkpoint_begin: the first shard that writes over an existing
+    valid checkpoint of the same size must itself leave no valid header -- or half-rewritten
+    records would pass for the old, complete file."""
+    path = tmp_path / "whole.ckp"
+    total = 10_000
+    with Sim.new(total, psim.GEN_FILLED) as whole:
+        whole.save_checkpoint(path, step=5)
+    assert psim.checkpoint_info(path)["step"] == 5
+    with Sim.new_shard(6000, 0, total, psim.GEN_UNIFORM) as a, \
+            Sim.new_shard(4000, 6000, total, psim.GEN_UNIFORM) as b:
+        a.save_checkpoint(path)                          # no begin; b never writes
+        with pytest.raises(psim.PsimError) as e:
+            psim.checkpoint_info(path)
+        assert e.value.code == 5
+        b.save_checkpoint(path)
+        with pytest.raises(psim.PsimError):
+            psim.checkpoint_info(path)                   # still none: only the commit makes one
+        b.commit_checkpoint(path, step=9)
+        assert psim.checkpoint_info(path)["step"] == 9
+        want = np.concatenate([a.download_aos(), b.download_aos()])
+    assert psim.read_checkpoint_records(path).tobytes() == want.tobytes()
