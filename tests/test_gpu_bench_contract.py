@@ -307,9 +307,9 @@ def test_strong_scaling_line_at_four_and_eight_ranks(world):
 def test_an_abandoned_exchange_check_is_reported_and_fails_the_run():
     """The check after the headline may hang or fail on a machine where the headline ran: the
     line must still go out (with the error in it), and the run must NOT report success.  Here
-    the watchdog is given half a second, less than the check needs."""
+    the watchdog is given 50 ms, less than the check needs to set itself up."""
     r, lines = launch_ranks(2, "--steps", "5", "--warmup", "2", "--particles", "1000000",
-                            port=29591, env_extra={"PSIM_BENCH_EXCHANGE_CHECK_SECONDS": "0.5"})
+                            port=29591, env_extra={"PSIM_BENCH_EXCHANGE_CHECK_SECONDS": "0.05"})
     assert r.returncode != 0, "an abandoned check must not exit with status 0"
     assert len(lines) == 1, r.stdout[:1000]
     out = json.loads(lines[0])
