@@ -312,6 +312,15 @@ void psim_host_free(void *ptr);
  * (src/simulation/cpu.rs:116-120) overlaps the transfer of frame k with its own work. */
 int psim_download_aos_async(psim_handle *h, psim_particle *dst_pinned, uint64_t first, uint64_t n);
 
+/* Waits for the most recent psim_download_aos_async into `dst_pinned` -- and for nothing that
+ * was enqueued after it.  This is what lets a staged frame loop run one frame ahead: per
+ * frame it enqueues psim_update and the download of frame k into one of two page-locked
+ * buffers, THEN waits for the download of frame k-1 into the other and hands that to the
+ * renderer (queue.write_buffer, src/simulation/cpu.rs:116-120) while the device is already
+ * working on frame k; the renderer sees every frame one frame late.  The handle tracks its
+ * four most recent destinations; PSIM_ERR_INVALID when none into `dst_pinned` is pending. */
+int psim_download_aos_wait(psim_handle *h, const psim_particle *dst_pinned);
+
 /* Copies positions and velocities of particles [first, first+n) to / from HOST
  * memory as six consecutive arrays of n floats: px | py | pz | vx | vy | vz.
  * Synchronous. */

@@ -206,6 +206,8 @@ public:
     {
         check(psim_download_aos_async(h_, out.data(), first, out.size()));
     }
+    // Waits for the most recent download_async into `out` and nothing enqueued after it.
+    void download_wait(const PinnedParticles &out) { check(psim_download_aos_wait(h_, out.data())); }
     void upload(const PinnedParticles &particles, uint64_t first = 0)
     {
         check(psim_upload_aos(h_, particles.data(), first, particles.size()));

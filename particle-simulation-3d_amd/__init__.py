@@ -155,6 +155,7 @@ ABI = {
     "psim_download_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_upload_aos": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_download_aos_async": (c_int, [_P, _P, c_uint64, c_uint64]),
+    "psim_download_aos_wait": (c_int, [_P, _P]),
     "psim_host_alloc": (c_int, [POINTER(_P), c_uint64]),
     "psim_host_free": (None, [_P]),
     "psim_download_soa": (c_int, [_P, _P, c_uint64, c_uint64]),
@@ -392,6 +393,11 @@ class HipParticleSimulation:
             raise ValueError("out must be a contiguous PARTICLE_DTYPE array of at least n records")
         _check(self._lib.psim_download_aos_async(self._h, out.ctypes.data_as(c_void_p), first, n))
         return out[:n]
+
+    def download_aos_wait(self, out):
+        """Waits for the most recent download_aos_async into `out`, and for nothing enqueued
+        after it (a staged frame loop runs one frame ahead this way)."""
+        _check(self._lib.psim_download_aos_wait(self._h, out.ctypes.data_as(c_void_p)))
 
     def upload_aos(self, particles, first=0):
         arr = np.ascontiguousarray(particles, dtype=PARTICLE_DTYPE)

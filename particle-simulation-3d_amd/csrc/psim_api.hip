@@ -153,6 +153,13 @@ struct psim_handle {
     psim_particle *bounce = nullptr;           // two page-locked slots for pageable downloads
     hipEvent_t bounce_done[2] = {nullptr, nullptr};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // the most recent asynchronous downloads, by destination: what psim_download_aos_wait waits for
+    struct PendingDownload {
+        const void *dst = nullptr;
+        hipEvent_t done = nullptr;
+        uint64_t age = 0;
+    } downloads[4];
+    uint64_t download_clock = 0;
     TuningOverrides overrides;
 };
 
@@ -515,6 +522,8 @@ PSIM_API void psim_destroy(psim_handle *h)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->bounce_done)
         if (e) (void)hipEventDestroy(e);
+    for (auto &d : h->downloads)
+        if (d.done) (void)hipEventDestroy(d.done);
     if (h->slab) (void)hipFree(h->slab);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1065,7 +1074,39 @@ PSIM_API int psim_download_aos_async(psim_handle *h, psim_particle *dst_pinned, 
                                      uint64_t n)
 {
     CHECK_HANDLE(h);
-    return enqueue_download_aos(h, dst_pinned, first, n);
+    int rc = enqueue_download_aos(h, dst_pinned, first, n);
+    if (rc != PSIM_OK || n == 0) return rc;
+    // Remember where this download ends in the stream, under its destination: the entry of the
+    // same destination, else a free one, else the oldest.
+    psim_handle::PendingDownload *slot = nullptr;
+    for (auto &d : h->downloads)
+        if (!slot && d.dst == dst_pinned) slot = &d;
+    for (auto &d : h->downloads)
+        if (!slot && d.dst == nullptr) slot = &d;
+    if (!slot) {
+        slot = &h->downloads[0];
+        for (auto &d : h->downloads)
+            if (d.age < slot->age) slot = &d;
+    }
+    if (!slot->done) HIP_TRY(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(slot->done, h->stream));
+    slot->dst = dst_pinned;
+    slot->age = ++h->download_clock;
+    return PSIM_OK;
+}
+
+PSIM_API int psim_download_aos_wait(psim_handle *h, const psim_particle *dst_pinned)
+{
+    CHECK_HANDLE(h);
+    if (!dst_pinned) return fail(PSIM_ERR_INVALID, "null destination");
+    for (auto &d : h->downloads)
+        if (d.dst == dst_pinned) {
+            HIP_TRY(hipEventSynchronize(d.done));
+            d.dst = nullptr;
+            return PSIM_OK;
+        }
+    return fail(PSIM_ERR_INVALID, "no asynchronous download into %p is pending (only the four "
+                "most recent destinations are tracked)", (const void *)dst_pinned);
 }
 
 PSIM_API int psim_upload_aos(psim_handle *h, const psim_particle *src_host, uint64_t first,

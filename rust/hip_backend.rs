@@ -1,7 +1,8 @@
 //! `src/simulation/hip.rs` -- the MI355X backend of the application, beside `cpu.rs` and
 //! `compute.rs`: `trait ParticleSimulation` (`src/simulation/mod.rs:21-50`) over the C ABI of
 //! `libpsim_hip.so` (crate `psim-sys`).  Not compiled in this repository (no Rust toolchain
-//! in its environment); every call below is a declaration of `psim-sys/src/lib.rs`.
+//! in its environment); every call below is a declaration of `psim-sys/src/lib.rs`, and the
+//! call sequence of `update` is the one `tests/cpp/staged_frames.cpp` runs and checks.
 //!
 //! To wire it in:
 //!   * `src/simulation/mod.rs:9-13`: `pub enum SimulationMethod { Cpu, ComputeShader, Hip }`
@@ -29,20 +30,27 @@ fn check(rc: c_int) {
     }
 }
 
+/// The renderer draws from a wgpu vertex buffer in the 64-byte Particle layout
+/// (src/renderer.rs:32-67).  Until that buffer is shared with HIP, frames are staged
+/// through host memory as the CPU backend does (src/simulation/cpu.rs:116-120) -- through
+/// TWO page-locked buffers from psim_host_alloc, so that the device can fill one with frame k
+/// while the other, holding frame k-1, is handed to wgpu.  `update` therefore never waits for
+/// the work it has just enqueued; the price is that the renderer sees every frame one frame
+/// late (and, while paused, the frame before the last one computed).
 pub struct HipParticleSimulation {
     handle: *mut PsimHandle,
-    // The renderer draws from a wgpu vertex buffer in the 64-byte Particle layout
-    // (src/renderer.rs:32-67).  Until that buffer is shared with HIP, frames are staged
-    // through host memory as the CPU backend does (src/simulation/cpu.rs:116-120), in
-    // page-locked memory from psim_host_alloc.
-    staging: *mut Particle,
+    staging: [*mut Particle; 2],
     staging_len: usize,
+    /// staging buffer with a download in flight: frame `frame - 1`
+    in_flight: Option<usize>,
+    frame: u64,
     particle_buffer: wgpu::Buffer,
 }
 
 fn alloc_staging(n: usize) -> *mut Particle {
     let mut p: *mut c_void = std::ptr::null_mut();
-    check(unsafe { psim_host_alloc(&mut p, (n as u64) * 64) });
+    // a set of 0 particles still gets a (64-byte) buffer: nothing below special-cases it
+    check(unsafe { psim_host_alloc(&mut p, (n.max(1) as u64) * 64) });
     p as *mut Particle
 }
 
@@ -53,6 +61,35 @@ fn vertex_buffer(device: &wgpu::Device, count: u32) -> wgpu::Buffer {
         usage: wgpu::BufferUsages::COPY_DST | wgpu::BufferUsages::VERTEX,
         mapped_at_creation: false,
     })
+}
+
+impl HipParticleSimulation {
+    /// The current particles into the vertex buffer, waiting for them: what the reference's
+    /// backends do in `new`, `resize_buffer` and `reset` (cpu.rs:24-28, :143-157, :181-185;
+    /// compute.rs:28-34, :187-189, :214-215), so that the renderer has the new set even while
+    /// the simulation is paused (app.rs:283 skips `update` then).
+    fn upload_now(&mut self, queue: &wgpu::Queue) {
+        self.in_flight = None; // whatever was on its way belongs to the old set
+        if self.staging_len == 0 {
+            return;
+        }
+        let staging = self.staging[0] as *mut PsimParticle;
+        check(unsafe { psim_download_aos(self.handle, staging, 0, self.staging_len as u64) });
+        let frame = unsafe { std::slice::from_raw_parts(self.staging[0], self.staging_len) };
+        queue.write_buffer(&self.particle_buffer, 0, bytemuck::cast_slice(frame));
+    }
+
+    fn resize_staging(&mut self, device: &wgpu::Device, new_count: u32) {
+        if new_count as usize != self.staging_len {
+            check(unsafe { psim_sync(self.handle) }); // no download may still write the old buffers
+            for s in self.staging.iter_mut() {
+                unsafe { psim_host_free(*s as *mut c_void) };
+                *s = alloc_staging(new_count as usize);
+            }
+            self.staging_len = new_count as usize;
+            self.particle_buffer = vertex_buffer(device, new_count);
+        }
+    }
 }
 
 impl ParticleSimulation for HipParticleSimulation {
@@ -66,10 +103,19 @@ impl ParticleSimulation for HipParticleSimulation {
         check(unsafe {
             psim_create(&mut handle, initial_particle_count, generation(generation_mode), 0)
         });
+        // `new` has no queue (mod.rs:22-29), so the first frame reaches the vertex buffer with
+        // the first `update`, `resize_buffer` or `reset`; a caller that may start paused adds
+        // `sim.reset(device, queue, mode)` after `new` (the reference's backends fill their
+        // buffer with create_buffer_init, which needs no queue: cpu.rs:24-28).
         Self {
             handle,
-            staging: alloc_staging(initial_particle_count as usize),
+            staging: [
+                alloc_staging(initial_particle_count as usize),
+                alloc_staging(initial_particle_count as usize),
+            ],
             staging_len: initial_particle_count as usize,
+            in_flight: None,
+            frame: 0,
             particle_buffer: vertex_buffer(device, initial_particle_count),
         }
     }
@@ -84,27 +130,39 @@ impl ParticleSimulation for HipParticleSimulation {
         // SimParams is #[repr(C)] with the layout of psim_sim_params (mod.rs:52-67)
         let params = params as *const SimParams as *const PsimSimParams;
         check(unsafe { psim_update(self.handle, params) }); // asynchronous
-        // hand the frame to the renderer
-        let staging = self.staging as *mut PsimParticle;
-        check(unsafe { psim_download_aos(self.handle, staging, 0, self.staging_len as u64) });
-        let frame = unsafe { std::slice::from_raw_parts(self.staging, self.staging_len) };
-        queue.write_buffer(&self.particle_buffer, 0, bytemuck::cast_slice(frame));
+        if self.staging_len == 0 {
+            return;
+        }
+        // frame k: transposed and copied out behind the update, into the buffer the renderer
+        // is not being fed from
+        let slot = (self.frame & 1) as usize;
+        let n = self.staging_len as u64;
+        check(unsafe {
+            psim_download_aos_async(self.handle, self.staging[slot] as *mut PsimParticle, 0, n)
+        });
+        // frame k-1 has had a whole frame's time to arrive: hand it to the renderer while the
+        // device works on frame k
+        if let Some(prev) = self.in_flight {
+            check(unsafe {
+                psim_download_aos_wait(self.handle, self.staging[prev] as *const PsimParticle)
+            });
+            let frame = unsafe { std::slice::from_raw_parts(self.staging[prev], self.staging_len) };
+            queue.write_buffer(&self.particle_buffer, 0, bytemuck::cast_slice(frame));
+        }
+        self.in_flight = Some(slot);
+        self.frame += 1;
     }
 
     fn resize_buffer(
         &mut self,
         device: &wgpu::Device,
-        _queue: &wgpu::Queue,
+        queue: &wgpu::Queue,
         new_count: u32,
         generation_mode: SphereGeneration,
     ) {
         check(unsafe { psim_resize(self.handle, new_count, generation(generation_mode)) });
-        if new_count as usize != self.staging_len {
-            unsafe { psim_host_free(self.staging as *mut c_void) };
-            self.staging = alloc_staging(new_count as usize);
-            self.staging_len = new_count as usize;
-            self.particle_buffer = vertex_buffer(device, new_count);
-        }
+        self.resize_staging(device, new_count);
+        self.upload_now(queue); // cpu.rs:153-157, compute.rs:187-189
     }
 
     fn get_particle_buffer(&self) -> &wgpu::Buffer {
@@ -122,10 +180,11 @@ impl ParticleSimulation for HipParticleSimulation {
     fn reset(
         &mut self,
         _device: &wgpu::Device,
-        _queue: &wgpu::Queue,
+        queue: &wgpu::Queue,
         generation_mode: SphereGeneration,
     ) {
         check(unsafe { psim_reset(self.handle, generation(generation_mode)) });
+        self.upload_now(queue); // cpu.rs:181-185, compute.rs:214-215
     }
 
     fn is_paused(&self) -> bool {
@@ -140,7 +199,10 @@ impl ParticleSimulation for HipParticleSimulation {
 impl Drop for HipParticleSimulation {
     fn drop(&mut self) {
         unsafe {
-            psim_host_free(self.staging as *mut c_void);
+            psim_sync(self.handle); // a download may still be writing the staging buffers
+            for s in self.staging {
+                psim_host_free(s as *mut c_void);
+            }
             psim_destroy(self.handle)
         }
     }
@@ -167,10 +229,13 @@ impl ShardedRank {
         check(unsafe { psim_exchange_rendezvous_file(path.as_ptr(), rank, id.as_mut_ptr(), 60_000) });
         let mut exchange = std::ptr::null_mut();
         check(unsafe { psim_exchange_create(&mut exchange, handle, id.as_ptr(), rank, world) });
+        // a rank that dies must not leave the others hanging in their next collective
+        check(unsafe { psim_exchange_set_timeout(exchange, 30_000) });
         Self { handle, exchange }
     }
 
     /// One frame: this rank's attractor joins the others', all are applied (asynchronous).
+    /// Panics (psim error 6) when the exchange has given up on a rank that has gone.
     pub fn step(&mut self, params: &PsimSimParams, mine: &PsimAttractor) {
         check(unsafe { psim_exchange_step(self.exchange, params, mine) });
     }

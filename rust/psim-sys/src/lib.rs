@@ -159,6 +159,7 @@ extern "C" {
     pub fn psim_host_alloc(out: *mut *mut c_void, bytes: u64) -> c_int;
     pub fn psim_host_free(ptr: *mut c_void);
     pub fn psim_download_aos_async(h: *mut PsimHandle, dst_pinned: *mut PsimParticle, first: u64, n: u64) -> c_int;
+    pub fn psim_download_aos_wait(h: *mut PsimHandle, dst_pinned: *const PsimParticle) -> c_int;
     pub fn psim_download_soa(h: *mut PsimHandle, dst_host: *mut f32, first: u64, n: u64) -> c_int;
     pub fn psim_upload_soa(h: *mut PsimHandle, src_host: *const f32, first: u64, n: u64) -> c_int;
     pub fn psim_export_aos_device(h: *mut PsimHandle, dst_device: *mut PsimParticle, first: u64, n: u64) -> c_int;

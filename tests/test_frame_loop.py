@@ -56,3 +56,24 @@ def test_frame_loop_matches_oracle_replay(tmp_path, count, generation):
     # the script visited colour modes 1 and 2 and went back to 0: colours keep the last
     # computed value (CPU semantics, cpu.rs:106), they are not reset to initial_color
     assert got["color"].tobytes() != got["initial_color"].tobytes()
+
+
+STAGED = os.path.join(CPP_DIR, "staged_frames")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("count,frames", [(1, 5), (70_001, 25), (1_000_000, 12)])
+def test_staged_frames_one_frame_ahead_deliver_the_blocking_loops_frames(count, frames):
+    """tests/cpp/staged_frames.cpp makes the calls of rust/hip_backend.rs's `update`: the
+    pipelined loop (psim_update + psim_download_aos_async of frame k, then
+    psim_download_aos_wait for frame k-1) must hand the renderer exactly the frames the
+    blocking loop hands it, one frame later (the program compares the hashes itself)."""
+    if not os.access(STAGED, os.X_OK):
+        build()
+    r = subprocess.run([STAGED, str(count), str(frames), "check"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocking_fps, pipelined_fps, blocking_wait, pipelined_wait = map(float, r.stdout.split())
+    assert blocking_fps > 0 and pipelined_fps > 0
+    print(f"{count} particles: {blocking_fps:.0f} -> {pipelined_fps:.0f} frames/s (with the "
+          f"frame hashed), host waits {blocking_wait:.3f} -> {pipelined_wait:.3f} ms per frame")
