@@ -336,6 +336,27 @@ int psim_import_aos_device(psim_handle *h, const psim_particle *src_device, uint
 /* Raw SoA device pointers. */
 int psim_device_soa(psim_handle *h, psim_soa_view *view);
 
+/* The device-resident replacement of `get_particle_buffer` (src/simulation/mod.rs:44).  The
+ * reference's compute backend keeps the particle buffer on the device and the renderer draws
+ * straight from it (src/simulation/compute.rs:28-34, src/custom_renderer.rs:36-38, instance
+ * layout src/renderer.rs:32-67): no frame crosses the host link.  This call gives a renderer
+ * in another API (Vulkan under wgpu, or another process) the same thing: a device buffer of
+ * the handle's capacity in 64-byte `Particle` records, owned by the handle, together with a
+ * NEW dma-buf file descriptor that refers to it (the caller closes it after importing; Vulkan
+ * imports it with VK_EXT_external_memory_dma_buf, HIP with hipImportExternalMemory as an
+ * opaque descriptor).  Fill it whenever a frame is wanted with
+ *     psim_export_aos_device(h, *device_ptr_out, 0, psim_particle_count(h))
+ * which runs on the handle's stream behind the updates; the importer must not read before that
+ * has finished (psim_sync, or an event on psim_get_stream).  The buffer lives until
+ * psim_destroy or until the set outgrows it: after a psim_resize that enlarged the storage,
+ * call again and import the new descriptor (an importer's mapping of the old memory stays
+ * valid, and stale, until it lets go).  The buffer is a physical allocation of its own
+ * (hipMemCreate), so the descriptor refers to exactly these records from offset 0;
+ * *bytes_out is its size, the records rounded up to the allocation granularity.
+ * PSIM_ERR_HIP when the runtime cannot allocate or export such memory. */
+int psim_shared_aos(psim_handle *h, psim_particle **device_ptr_out, int *dmabuf_fd_out,
+                    uint64_t *bytes_out);
+
 /* Order-independent checksums of the active state, computed on the device with
  * wavefront reductions: out[k] = sum over particles of the uint32 bit pattern of
  * component k (k = 0..5 : px,py,pz,vx,vy,vz) as a uint64 (mod 2^64).

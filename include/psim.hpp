@@ -206,6 +206,24 @@ public:
     {
         check(psim_download_aos_async(h_, out.data(), first, out.size()));
     }
+    // The device buffer of 64-byte records a renderer in another API or process maps
+    // (psim_shared_aos): its device pointer, a new dma-buf descriptor (the caller closes it)
+    // and its size.  export_to(ptr) fills it on the handle's stream.
+    struct SharedRecords {
+        Particle *device = nullptr;
+        int dmabuf_fd = -1;
+        uint64_t bytes = 0;
+    };
+    SharedRecords shared_records()
+    {
+        SharedRecords r;
+        check(psim_shared_aos(h_, &r.device, &r.dmabuf_fd, &r.bytes));
+        return r;
+    }
+    void export_to(Particle *device_buffer)
+    {
+        check(psim_export_aos_device(h_, device_buffer, 0, psim_particle_count(h_)));
+    }
     // Waits for the most recent download_async into `out` and nothing enqueued after it.
     void download_wait(const PinnedParticles &out) { check(psim_download_aos_wait(h_, out.data())); }
     void upload(const PinnedParticles &particles, uint64_t first = 0)

@@ -163,6 +163,7 @@ ABI = {
     "psim_export_aos_device": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_import_aos_device": (c_int, [_P, _P, c_uint64, c_uint64]),
     "psim_device_soa": (c_int, [_P, POINTER(SoaView)]),
+    "psim_shared_aos": (c_int, [_P, POINTER(_P), POINTER(c_int), POINTER(c_uint64)]),
     "psim_checksum": (c_int, [_P, POINTER(c_uint64)]),
     "psim_checkpoint_write": (c_int, [_P, c_char_p, c_uint64]),
     "psim_checkpoint_begin": (c_int, [c_char_p]),
@@ -424,6 +425,14 @@ class HipParticleSimulation:
     def import_aos_device(self, src_device_ptr, first=0, n=None):
         n = self.get_particle_count() - first if n is None else n
         _check(self._lib.psim_import_aos_device(self._h, c_void_p(src_device_ptr), first, n))
+
+    def shared_aos(self):
+        """(device address, new dma-buf file descriptor, bytes) of the handle's device buffer
+        of 64-byte records for a renderer in another API or process; fill it with
+        export_aos_device(address).  The caller closes the descriptor."""
+        ptr, fd, size = c_void_p(), c_int(-1), c_uint64(0)
+        _check(self._lib.psim_shared_aos(self._h, byref(ptr), byref(fd), byref(size)))
+        return int(ptr.value), int(fd.value), int(size.value)
 
     def checksum(self):
         out = (c_uint64 * 6)()

@@ -125,6 +125,9 @@ psim::LaunchTuning batch_tuning_for(uint32_t n, uint32_t steps, const TuningOver
 
 }  // namespace
 
+struct psim_handle;
+namespace { void release_shared_aos(psim_handle *h); }
+
 struct psim_handle {
     int device = 0;
     int num_cus = 0;
@@ -160,6 +163,11 @@ struct psim_handle {
         uint64_t age = 0;
     } downloads[4];
     uint64_t download_clock = 0;
+    // The records as a device buffer other APIs can map: a physical allocation of its own
+    // (hipMemCreate), so that the exported descriptor refers to exactly this buffer.
+    psim_particle *shared_aos = nullptr;
+    uint64_t shared_bytes = 0;                 // mapped size (a multiple of the granularity)
+    hipMemGenericAllocationHandle_t shared_memory = nullptr;
     TuningOverrides overrides;
 };
 
@@ -516,6 +524,7 @@ PSIM_API void psim_destroy(psim_handle *h)
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
     if (h->aos_stage) (void)hipFree(h->aos_stage);
+    release_shared_aos(h);                      // importers keep their own reference
     if (h->bounce) (void)hipHostFree(h->bounce);
     if (h->list_host) (void)hipHostFree(h->list_host);
     for (hipEvent_t e : h->list_copied)
@@ -1209,6 +1218,89 @@ PSIM_API int psim_import_aos_device(psim_handle *h, const psim_particle *src_dev
         return fail(PSIM_ERR_INVALID, "AoS device buffer must be non-null and 16-byte aligned");
     h->colours_changed = true;
     HIP_TRY(psim::launch_import_aos(h->soa, (uint32_t)first, (uint32_t)n, src_device, h->stream));
+    return PSIM_OK;
+}
+
+namespace {
+
+void release_shared_aos(psim_handle *h)
+{
+    if (h->shared_aos) {
+        (void)hipMemUnmap(h->shared_aos, h->shared_bytes);
+        (void)hipMemAddressFree(h->shared_aos, h->shared_bytes);
+    }
+    if (h->shared_memory) (void)hipMemRelease(h->shared_memory);
+    h->shared_aos = nullptr;
+    h->shared_memory = nullptr;
+    h->shared_bytes = 0;
+}
+
+// hipMalloc serves small requests out of larger allocations, and a descriptor exported for
+// such a range refers to the whole underlying allocation (an importer would see other data at
+// offset 0).  So the shared buffer is a physical allocation of its own, mapped at an address
+// range of its own.
+int create_shared_aos(psim_handle *h)
+{
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = h->device;
+    prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+    size_t granularity = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&granularity, &prop, hipMemAllocationGranularityMinimum));
+    if (granularity == 0) granularity = 2u << 20;
+    const uint64_t want = (uint64_t)h->capacity * sizeof(psim_particle);
+    const uint64_t bytes = (want + granularity - 1) / granularity * granularity;
+    HIP_TRY(hipMemCreate(&h->shared_memory, (size_t)bytes, &prop, 0));
+    void *va = nullptr;
+    hipError_t e = hipMemAddressReserve(&va, (size_t)bytes, granularity, nullptr, 0);
+    if (e == hipSuccess) {
+        e = hipMemMap(va, (size_t)bytes, 0, h->shared_memory, 0);
+        if (e != hipSuccess) (void)hipMemAddressFree(va, (size_t)bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemRelease(h->shared_memory);
+        h->shared_memory = nullptr;
+        return fail(PSIM_ERR_HIP, "mapping the shared record buffer failed: %s", hipGetErrorString(e));
+    }
+    h->shared_aos = static_cast<psim_particle *>(va);
+    h->shared_bytes = bytes;
+    hipMemAccessDesc access;
+    memset(&access, 0, sizeof(access));
+    access.location = prop.location;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(va, (size_t)bytes, &access, 1);
+    if (e != hipSuccess) {
+        release_shared_aos(h);
+        return fail(PSIM_ERR_HIP, "hipMemSetAccess on the shared record buffer failed: %s",
+                    hipGetErrorString(e));
+    }
+    return PSIM_OK;
+}
+
+}  // namespace
+
+PSIM_API int psim_shared_aos(psim_handle *h, psim_particle **device_ptr_out, int *dmabuf_fd_out,
+                             uint64_t *bytes_out)
+{
+    CHECK_HANDLE(h);
+    if (!device_ptr_out || !dmabuf_fd_out || !bytes_out)
+        return fail(PSIM_ERR_INVALID, "null output pointer");
+    *device_ptr_out = nullptr, *dmabuf_fd_out = -1, *bytes_out = 0;
+    if (h->shared_aos && h->shared_bytes < (uint64_t)h->capacity * sizeof(psim_particle)) {
+        HIP_TRY(hipStreamSynchronize(h->stream));    // the set has outgrown it; an export may still write it
+        release_shared_aos(h);
+    }
+    if (!h->shared_aos) {
+        const int rc = create_shared_aos(h);
+        if (rc != PSIM_OK) return rc;
+    }
+    int fd = -1;
+    HIP_TRY(hipMemExportToShareableHandle(&fd, h->shared_memory, hipMemHandleTypePosixFileDescriptor, 0));
+    *device_ptr_out = h->shared_aos;
+    *dmabuf_fd_out = fd;
+    *bytes_out = h->shared_bytes;
     return PSIM_OK;
 }
 

@@ -165,6 +165,7 @@ extern "C" {
     pub fn psim_export_aos_device(h: *mut PsimHandle, dst_device: *mut PsimParticle, first: u64, n: u64) -> c_int;
     pub fn psim_import_aos_device(h: *mut PsimHandle, src_device: *const PsimParticle, first: u64, n: u64) -> c_int;
     pub fn psim_device_soa(h: *mut PsimHandle, view: *mut PsimSoaView) -> c_int;
+    pub fn psim_shared_aos(h: *mut PsimHandle, device_ptr_out: *mut *mut PsimParticle, dmabuf_fd_out: *mut c_int, bytes_out: *mut u64) -> c_int;
     pub fn psim_checksum(h: *mut PsimHandle, out: *mut u64) -> c_int;
     pub fn psim_checkpoint_write(h: *mut PsimHandle, path: *const c_char, step: u64) -> c_int;
     pub fn psim_checkpoint_begin(path: *const c_char) -> c_int;
