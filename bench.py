@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 
 ALGORITHMIC_BYTES_PER_UPDATE = 48      # 6 fp32 read + 6 fp32 written, colour mode 0
 HBM_PEAK_GBPS = 8000.0                 # MI355X HBM3E datasheet peak
-KERNEL_SOURCES = ("psim_kernels.hip", "psim_kernels.h", "psim_threshold.h", "Makefile")
+KERNEL_SOURCES = ("psim_kernels.hip", "psim_kernels.h", "psim_threshold.h", "psim_tuning.h",
+                  "psim_tuning.cpp", "Makefile")
 
 # name, particles per GPU as written (the 8-GPU configurations divided by 8), total when the
 # particle count is held fixed instead (--scaling strong), workload

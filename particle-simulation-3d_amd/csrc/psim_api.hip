@@ -1537,4 +1537,4 @@ PSIM_API int psim_launch_occupancy(psim_handle *h, uint32_t n_attractors, uint32
 
 PSIM_API const char *psim_last_error(void) { return g_error; }
 
-PSIM_API const char *psim_version(void) { return "psim-hip 0.2 (gfx950)"; }
+PSIM_API const char *psim_version(void) { return "psim-hip 0.3 (gfx950)"; }

@@ -122,6 +122,8 @@ def test_null_arguments_are_rejected_without_a_device():
     assert lib.psim_set_resize_semantics(None, 1) == 1
     assert lib.psim_resize_semantics(None) == 0
     assert lib.psim_download_aos_async(None, None, 0, 0) == 1
+    assert lib.psim_download_aos_wait(None, None) == 1
+    assert lib.psim_shared_aos(None, None, None, None) == 1
     g = ctypes.c_void_p()
     ids = (ctypes.c_int * 2)(0, 0)
     assert lib.psim_group_create(None, 10, ids, 2, 2) == 1
@@ -133,6 +135,31 @@ def test_null_arguments_are_rejected_without_a_device():
     assert lib.psim_group_particle_count(None) == 0 and lib.psim_group_shards(None) == 0
     assert lib.psim_group_shard(None, 0) is None
     lib.psim_group_destroy(None)                                # no-op
+
+
+def test_tuning_overrides_are_named_and_checked():
+    """psim_debug_set_tuning is the one way to change a launch shape; it needs no device, knows
+    its names and refuses others.  (That the environment alone changes nothing is a GPU test:
+    tests/test_gpu_launch_shapes.py.)"""
+    lib = psim.load_library()
+    for name in ("nt", "reserve_lds", "max_blocks", "skew_bytes", "queue_from", "aos_stream",
+                 "aos_reserve", "aos_block", "aos_ppl", "checksum_blocks", "exchange_event_fences",
+                 "exchange_comm_priority"):
+        assert lib.psim_debug_set_tuning(name.encode(), 1) == 0, name
+        assert lib.psim_debug_set_tuning(name.encode(), -1) == 0, name
+    assert lib.psim_debug_set_tuning(b"PSIM_NT", 1) == 1
+    assert b"unknown tuning override" in lib.psim_last_error()
+    assert lib.psim_debug_set_tuning(None, 1) == 1
+    with pytest.raises(psim.PsimError):
+        psim.debug_set_tuning("no_such_override", 0)
+    # the automatic launch shape does not move with an override: psim_launch_shape reports the
+    # library's own choice
+    before = psim.launch_shape(100_000_000, 1)
+    psim.debug_set_tuning("reserve_lds", 4096)
+    try:
+        assert psim.launch_shape(100_000_000, 1) == before
+    finally:
+        psim.debug_set_tuning("reserve_lds", -1)
 
 
 @pytest.mark.skipif(T.gpu_available(), reason="a GPU is present")

@@ -72,6 +72,8 @@ def test_argument_validation():
     assert x.value is None
     assert lib.psim_exchange_step(None, None, None) == 1
     assert lib.psim_exchange_sync(None) == 1
+    assert lib.psim_exchange_set_timeout(None, 1000) == 1
+    assert lib.psim_exchange_set_pacing(None, 0) == 1
     assert lib.psim_exchange_last_list(None, None) == 1
     assert lib.psim_exchange_world(None) == 0 and lib.psim_exchange_rank(None) == -1
     lib.psim_exchange_destroy(None)
