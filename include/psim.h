@@ -550,7 +550,9 @@ int psim_exchange_rendezvous_file(const char *path, int rank,
                                   uint8_t id[PSIM_EXCHANGE_ID_BYTES], uint32_t timeout_ms);
 
 /* Joins the communicator `id` as `rank` of `world` (at most PSIM_MAX_ATTRACTORS) on the
- * device of `h`; collective: returns once every rank has called it.  The handle stays the
+ * device of `h`; collective: returns once every rank has called it (RCCL's ncclCommInitRank
+ * waits without a limit: a launcher that can lose a rank before this point keeps its own
+ * watchdog; psim_exchange_set_timeout covers everything after it).  The handle stays the
  * caller's and must outlive the exchange. */
 int psim_exchange_create(psim_exchange **out, psim_handle *h,
                          const uint8_t id[PSIM_EXCHANGE_ID_BYTES], int rank, int world);

@@ -149,6 +149,26 @@ def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world, pacing,
         assert outs[r] == T.oracle_checksum_soa(T.aos_to_soa(want)), f"rank {r} of {world}"
 
 
+def test_ranks_may_pace_themselves_differently(tmp_path):
+    """The pacing is each rank's own business: rank 0 host-paced, rank 1 device-paced, rank 2
+    device-paced with a host that has other work per step (so it never runs ahead)."""
+    world, n, steps = 3, 50_003, 20
+    cpp_dir = build_c_hosts()
+    env = dict(os.environ, PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"))
+    how = {0: ("host",), 1: ("device",), 2: ("device", "nap_us=200")}
+    procs = {r: subprocess.Popen([os.path.join(cpp_dir, "exchange_loop"), str(r), str(world), "0",
+                                  str(n), str(steps), str(tmp_path / "id"), *how[r]], env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in reversed(range(world))}
+    outs = checksums_of(procs)
+    params = T.make_params(**C_HOST_PARAMS)
+    for r in range(world):
+        want = T.oracle_gen_uniform_aos(r * n, n)
+        for t in range(2 * steps):
+            want = T.oracle_update_aos(want, params, 1, c_host_attractors(world, t))
+        assert outs[r] == T.oracle_checksum_soa(T.aos_to_soa(want)), f"rank {r}"
+
+
 @pytest.mark.parametrize("pacing", ["host", "device"])
 def test_fifty_million_particles_over_eight_ranks_with_eight_attractors(tmp_path, pacing):
     """The 50 M-particle configuration in its own shape -- 8 ranks of 6.25 M particles, one

@@ -94,3 +94,39 @@ def test_capture_into_a_graph_replays_the_list():
         want = T.oracle_update_aos(want, params, 1, attractors)
         want = T.oracle_update_aos(want, params, 1, attractors[:12])
     T.assert_particles_equal(got, want, "graph replay")
+
+
+def test_capture_under_the_compute_shaders_colour_rule():
+    """Under PSIM_COLOR_RESET a step in colour mode 0 that follows a colouring step also
+    enqueues the device-to-device copy that resets the colours, and whether it does is decided
+    when the call is made -- at capture.  A graph captured in the colour state it is replayed in
+    (here: a colouring step, then a mode-0 step) must replay exactly what the same calls do
+    eagerly, and leave colour == initial colour."""
+    torch = pytest.importorskip("torch")
+    colouring = T.bench_params(gravity=0.3, color_mode=1)
+    plain = T.bench_params(gravity=0.3, color_mode=0)
+    attractors = attractor_list(12, 9, 20.0)
+    n = 40_000
+    stream = torch.cuda.Stream()
+    with Sim.new(n, psim.GEN_UNIFORM) as sim, Sim.new(n, psim.GEN_UNIFORM) as eager:
+        sim.set_color_semantics(psim.COLOR_RESET)
+        eager.set_color_semantics(psim.COLOR_RESET)
+        sim.set_stream(stream.cuda_stream)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            graph.capture_begin()
+            sim.update_multi_noalloc(colouring, attractors)
+            sim.update_multi_noalloc(plain, attractors)          # carries the colour reset
+            graph.capture_end()
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = sim.download_aos()
+        sim.set_stream(0)
+        for _ in range(2):
+            eager.update_multi_noalloc(colouring, attractors)
+            eager.update_multi_noalloc(plain, attractors)
+        want = eager.download_aos()
+    assert got.tobytes() == want.tobytes()
+    assert got["color"].tobytes() == got["initial_color"].tobytes()
+    assert (got["velocity"] != 0).any()
