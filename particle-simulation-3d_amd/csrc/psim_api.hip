@@ -1203,6 +1203,16 @@ PSIM_API int psim_export_aos_device(psim_handle *h, psim_particle *dst_device, u
     if (n == 0) return PSIM_OK;
     if (!dst_device || !aligned16(dst_device))
         return fail(PSIM_ERR_INVALID, "AoS device buffer must be non-null and 16-byte aligned");
+    // The one destination whose size is known here: a caller that kept the pointer of the
+    // shared record buffer across a resize that outgrew it must not write past its end.
+    if (h->shared_aos) {
+        const char *lo = reinterpret_cast<const char *>(h->shared_aos), *hi = lo + h->shared_bytes;
+        const char *d = reinterpret_cast<const char *>(dst_device);
+        if (d >= lo && d < hi && n * sizeof(psim_particle) > (uint64_t)(hi - d))
+            return fail(PSIM_ERR_INVALID, "%llu records do not fit the shared record buffer from "
+                        "there: call psim_shared_aos again after the set has grown",
+                        (unsigned long long)n);
+    }
     HIP_TRY(psim::launch_export_aos(h->soa, (uint32_t)first, (uint32_t)n, dst_device, h->stream));
     return PSIM_OK;
 }

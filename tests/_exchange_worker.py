@@ -22,11 +22,12 @@ from psim_testlib import psim  # noqa: E402
 par = importlib.import_module("particle-simulation-3d_amd.parallel")
 
 
-def one_rank_steps_equal_the_oracle(steps, pacing="device", switch_every=0):
+def one_rank_steps_equal_the_oracle(steps, pacing="device", switch_every=0, timeout_ms=0):
     n = 300_007
     params = T.bench_params(gravity=0.5, is_mouse_dragging=0, color_mode=2)
     runner = par.NativeMultiAttractorRunner(n, 0, 1, 0, params, psim.exchange_unique_id(),
-                                            force=60.0, radius=30.0, pacing=pacing)
+                                            force=60.0, radius=30.0, pacing=pacing,
+                                            timeout_ms=timeout_ms)
     try:
         for t in range(steps):
             if switch_every and t % switch_every == 0:   # the pacing may change between steps
@@ -149,6 +150,20 @@ def case_one_rank_steps_equal_the_oracle_40():
 
 def case_host_paced_steps_equal_the_oracle_40():
     one_rank_steps_equal_the_oracle(40, pacing="host")
+
+
+def case_with_a_timeout_set_host_paced_steps_equal_the_oracle_40():
+    """psim_exchange_set_timeout over the real RCCL: the polling waits and the questions to the
+    communicator (ncclCommGetAsyncError) change nothing while every rank is there."""
+    one_rank_steps_equal_the_oracle(40, pacing="host", timeout_ms=20_000)
+
+
+def case_with_a_timeout_set_device_paced_steps_equal_the_oracle_40():
+    one_rank_steps_equal_the_oracle(40, pacing="device", timeout_ms=20_000)
+
+
+def case_with_a_timeout_set_the_pacing_may_still_change():
+    one_rank_steps_equal_the_oracle(37, switch_every=5, timeout_ms=20_000)
 
 
 def case_pacing_switched_every_5_steps_equals_the_oracle():

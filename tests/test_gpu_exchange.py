@@ -35,6 +35,9 @@ CASES = [
     "case_pacing_switched_every_5_steps_equals_the_oracle",
     "case_three_thousand_small_steps_reuse_the_ring_correctly",
     "case_unknown_pacing_is_rejected",
+    "case_with_a_timeout_set_device_paced_steps_equal_the_oracle_40",
+    "case_with_a_timeout_set_host_paced_steps_equal_the_oracle_40",
+    "case_with_a_timeout_set_the_pacing_may_still_change",
 ]
 
 

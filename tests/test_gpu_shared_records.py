@@ -49,10 +49,12 @@ def test_the_shared_buffer_holds_the_records_and_follows_a_resize():
             reader.sync()
             assert reader.download_aos().tobytes() == want.tobytes()
             # growing the set beyond the storage retires the buffer: a new one, large enough
-            sim.resize_buffer(4 * n, psim.GEN_HOLLOW)
+            sim.resize_buffer(64 * n, psim.GEN_HOLLOW)
+            with pytest.raises(psim.PsimError, match="do not fit the shared record buffer"):
+                sim.export_aos_device(ptr)               # the old buffer: refused, not overrun
             ptr3, fd3, size3 = sim.shared_aos()
             os.close(fd3)
-            assert size3 >= 4 * n * 64
+            assert size3 >= 64 * n * 64
             sim.export_aos_device(ptr3)
             sim.sync()
         finally:
