@@ -15,7 +15,10 @@
 // The program checks that the pipelined loop delivers exactly the frames of the blocking loop,
 // each one frame later, and prints the frame rates of both.
 //
-// usage: staged_frames <particles> <frames> [check|time]
+// usage: staged_frames <particles> <frames> [check|time|nocopy]
+//   check   hash every delivered frame and compare the two loops (default)
+//   time    no hashing: the frame rates with the renderer-side copy
+//   nocopy  no hashing and no renderer-side copy: what the library and the host link alone allow
 // prints: blocking_fps pipelined_fps blocking_wait_ms pipelined_wait_ms
 //         (the waits: host time per frame spent inside the download / the wait call)
 #include <chrono>
@@ -62,12 +65,13 @@ psim::SimParams frame_params(int frame)
 int main(int argc, char **argv)
 {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s particles frames [check|time]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s particles frames [check|time|nocopy]\n", argv[0]);
         return 2;
     }
     const uint32_t n = static_cast<uint32_t>(std::strtoul(argv[1], nullptr, 10));
     const int frames = std::atoi(argv[2]);
     const bool check = argc < 4 || std::strcmp(argv[3], "check") == 0;
+    const bool copy = argc < 4 || std::strcmp(argv[3], "nocopy") != 0;
     try {
         psim::HipParticleSimulation sim(n, psim::SphereGeneration::Hollow);
         psim::PinnedParticles slot0(n), slot1(n);
@@ -84,7 +88,7 @@ int main(int argc, char **argv)
             const double w0 = now_ms();
             sim.download(slot0);
             waited += now_ms() - w0;
-            std::memcpy(vertex_buffer.data(), slot0.data(), bytes);
+            if (copy) std::memcpy(vertex_buffer.data(), slot0.data(), bytes);
             if (check) blocking.push_back(frame_hash(vertex_buffer.data(), n));
         }
         const double blocking_ms = (now_ms() - t0) / frames, blocking_wait = waited / frames;
@@ -101,7 +105,7 @@ int main(int argc, char **argv)
                 const double w0 = now_ms();
                 sim.download_wait(*slots[in_flight]);
                 waited += now_ms() - w0;
-                std::memcpy(vertex_buffer.data(), slots[in_flight]->data(), bytes);
+                if (copy) std::memcpy(vertex_buffer.data(), slots[in_flight]->data(), bytes);
                 if (check) pipelined.push_back(frame_hash(vertex_buffer.data(), n));
             }
             in_flight = k & 1;
