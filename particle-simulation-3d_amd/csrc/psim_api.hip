@@ -1084,7 +1084,7 @@ PSIM_API int psim_download_aos_async(psim_handle *h, psim_particle *dst_pinned, 
 {
     CHECK_HANDLE(h);
     int rc = enqueue_download_aos(h, dst_pinned, first, n);
-    if (rc != PSIM_OK || n == 0) return rc;
+    if (rc != PSIM_OK || !dst_pinned) return rc;     // (an empty range may come without a buffer)
     // Remember where this download ends in the stream, under its destination: the entry of the
     // same destination, else a free one, else the oldest.
     psim_handle::PendingDownload *slot = nullptr;

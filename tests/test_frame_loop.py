@@ -62,7 +62,7 @@ STAGED = os.path.join(CPP_DIR, "staged_frames")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("count,frames", [(1, 5), (70_001, 25), (1_000_000, 12)])
+@pytest.mark.parametrize("count,frames", [(0, 3), (1, 5), (70_001, 25), (1_000_000, 12)])
 def test_staged_frames_one_frame_ahead_deliver_the_blocking_loops_frames(count, frames):
     """tests/cpp/staged_frames.cpp makes the calls of rust/hip_backend.rs's `update`: the
     pipelined loop (psim_update + psim_download_aos_async of frame k, then

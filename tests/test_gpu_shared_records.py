@@ -18,7 +18,7 @@ CPP_DIR = os.path.join(T.ROOT, "tests", "cpp")
 Sim = psim.HipParticleSimulation
 
 
-@pytest.mark.parametrize("count,frames", [(1, 3), (70_001, 6), (2_000_000, 4)])
+@pytest.mark.parametrize("count,frames", [(0, 2), (1, 3), (70_001, 6), (2_000_000, 4)])
 def test_another_process_reads_every_frame_through_one_mapping(count, frames):
     """tests/cpp/shared_records.cpp: producer and consumer processes (forked before either
     touches the GPU); the consumer maps the descriptor once and must find every exported frame
