@@ -20,7 +20,8 @@ Prints ONE JSON line on rank 0: whole-job particle-updates/s over the timed step
 `roofline` (algorithmic bytes per launch / HIP-event launch duration against the HBM peak,
 and the HBM traffic measured with rocprofv3 counters when the committed summary under
 profiles/ was taken from this very build) and, at N = 1, `cpu_baseline` (the CPU restatement
-of the reference's update timed on the host cores).  At N > 1 the single-attractor
+of the reference's update timed on the host cores) and `sustained` (the same step held for
+seconds after the timed steps: the rate once clocks have settled).  At N > 1 the single-attractor
 configurations append `exchange_check`: a short run of the config-5 step over all ranks,
 outside the timed region, so that one multi-GPU run also shows what the collective delivers
 and costs.
@@ -80,6 +81,9 @@ def parse_args():
                     help="particles stepped by the CPU baseline (default: the GPU's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained-seconds", type=float, default=6.0,
+                    help="after the timed steps, keep stepping for about this long and report "
+                         "the rate held (`sustained`; 0: leave it out)")
     ap.add_argument("--no-exchange-check", action="store_true")
     return ap.parse_args()
 
@@ -389,6 +393,31 @@ def main():
         per_rank = [[float(v) for v in r.tolist()] for r in everyone]
     barrier()
 
+    # After the K timed steps: the same step for seconds on end, untimed by the headline.  K
+    # steps take milliseconds; this says what the device holds once clocks and temperature
+    # have settled (and keeps the GPU busy long enough for an outside sampler to see it).
+    sustained = None
+    if args.sustained_seconds > 0 and not rehearsal:
+        k = int(args.sustained_seconds * 1e3 / max(device_ms / args.steps, 1e-4))
+        k = max(args.steps, min(k, 1_000_000))
+        t1 = time.perf_counter()
+        sim.timer_start()
+        for _ in range(k):
+            step()
+        held_ms = sim.timer_stop()
+        finish()
+        sim.sync()
+        held_s = time.perf_counter() - t1
+        slowest = [held_s, held_ms]
+        if distributed:
+            t = torch.tensor(slowest, dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            slowest = [float(v) for v in t.tolist()]
+        sustained = {"steps": k, "seconds": slowest[0], "ms_per_step": slowest[0] / k * 1e3,
+                     "launch_ms": slowest[1] / k, "value": total * k / slowest[0],
+                     "unit": "particle-updates/s", "aggregation": "max over ranks"}
+        barrier()
+
     out = None
     if rank == 0:
         total_updates = total * args.steps
@@ -448,6 +477,8 @@ def main():
                 **identity,
             },
         }
+        if sustained is not None:
+            out["sustained"] = sustained
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample
             note = ""

@@ -17,7 +17,9 @@ def run_bench(*extra):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--steps", "5",
-                        "--warmup", "2", "--particles", "2000000", *extra],
+                        "--warmup", "2", "--particles", "2000000",
+                        *(() if "--sustained-seconds" in extra else ("--sustained-seconds", "0")),
+                        *extra],
                        capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -26,7 +28,7 @@ def run_bench(*extra):
 
 
 def test_single_workload_line():
-    out = run_bench("--cpu-sample", "1000000", "--cpu-seconds", "1")
+    out = run_bench("--cpu-sample", "1000000", "--cpu-seconds", "1", "--sustained-seconds", "0.5")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                 "roofline", "cpu_baseline"):
@@ -43,6 +45,10 @@ def test_single_workload_line():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert roof["algorithmic_bytes_per_launch"] == 48 * 2_000_000
     assert roof["traffic"] is None            # the committed counters are for the 100 M size
+    held = out["sustained"]
+    assert held["steps"] >= 5 and 0.2 < held["seconds"] < 5.0 and held["unit"] == out["unit"]
+    assert abs(held["value"] - 2_000_000 * held["steps"] / held["seconds"]) / held["value"] < 1e-6
+    assert 0 < held["launch_ms"] <= held["ms_per_step"] * 1.001
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert cpu["unit"] == "particle-updates/s" and "particles" in cpu["sample"]
@@ -83,7 +89,7 @@ def test_one_rank_under_the_launcher_uses_rccl():
                         "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", "29543", os.path.join(T.ROOT, "bench.py"),
                         "--gpus", "1", "--steps", "5", "--warmup", "2", "--particles", str(n),
-                        "--no-cpu-baseline"],
+                        "--no-cpu-baseline", "--sustained-seconds", "0.3"],
                        capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -91,6 +97,7 @@ def test_one_rank_under_the_launcher_uses_rccl():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["config"]["total_particles"] == n
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+    assert out["sustained"]["value"] > 0          # its reduction over the ranks ran on RCCL too
 
 
 @pytest.mark.parametrize("pacing", ["host", "device"])
@@ -122,7 +129,7 @@ def test_baseline_config_presets(config, per_gpu, workload):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
-           "--config", str(config), "--no-cpu-baseline"]
+           "--config", str(config), "--no-cpu-baseline", "--sustained-seconds", "0"]
     if not full_size:
         cmd += ["--particles", "3000000"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env)
@@ -324,7 +331,7 @@ def test_one_rank_under_the_launcher_measures_what_the_plain_run_measures():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PSIM_BENCH_REHEARSAL"):
         env.pop(k, None)
-    args = ["--steps", "40", "--warmup", "10", "--no-cpu-baseline"]
+    args = ["--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--sustained-seconds", "0"]
     plain = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), *args],
                            capture_output=True, text=True, timeout=280, env=env)
     assert plain.returncode == 0, plain.stderr[-3000:]
