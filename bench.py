@@ -85,6 +85,9 @@ def parse_args():
                     help="after the timed steps, keep stepping for about this long and report "
                          "the rate held (`sustained`; 0: leave it out)")
     ap.add_argument("--no-exchange-check", action="store_true")
+    ap.add_argument("--no-copy-yardstick", action="store_true",
+                    help="leave out roofline.device_copy (the runtime's device-to-device copy of "
+                         "the same bytes, timed in the same run at N = 1)")
     return ap.parse_args()
 
 
@@ -116,6 +119,30 @@ def cpu_baseline(sample, seconds):
         "sample": f"{sample} particles (the same synthetic state from particle 0 on, AoS 64 B) x "
                   f"{steps} steps in {dt:.2f} s; update loop only, no upload copy",
     }
+
+
+def copy_yardstick(torch, moved_bytes, reps=20):
+    """A yardstick taken in the same run on the same GPU: the runtime's own device-to-device
+    copy (torch's tensor copy) moving the bytes one update moves, half read and half written.
+    Nothing of the product runs here; it only says what a plain copy reaches on this box."""
+    words = max(moved_bytes // 2 // 4, 1)
+    src = torch.rand(words, dtype=torch.float32, device="cuda")
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    stop.record()
+    torch.cuda.synchronize()
+    ms = start.elapsed_time(stop) / reps
+    del src, dst
+    torch.cuda.empty_cache()
+    return {"what": "torch device-to-device copy of a float32 tensor, bytes read + written = the "
+                    "update's algorithmic bytes per launch", "bytes": words * 8,
+            "ms": ms, "achieved": words * 8 / (ms / 1e3) / 1e9, "unit": "GB/s"}
 
 
 def host_memory_allows(particles):
@@ -418,6 +445,10 @@ def main():
                      "unit": "particle-updates/s", "aggregation": "max over ranks"}
         barrier()
 
+    yardstick = None
+    if world == 1 and not rehearsal and not args.no_copy_yardstick:
+        yardstick = copy_yardstick(torch, ALGORITHMIC_BYTES_PER_UPDATE * n)
+
     out = None
     if rank == 0:
         total_updates = total * args.steps
@@ -479,6 +510,8 @@ def main():
         }
         if sustained is not None:
             out["sustained"] = sustained
+        if yardstick is not None:
+            out["roofline"]["device_copy"] = yardstick
         if world == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample
             note = ""

@@ -49,6 +49,9 @@ def test_single_workload_line():
     assert held["steps"] >= 5 and 0.2 < held["seconds"] < 5.0 and held["unit"] == out["unit"]
     assert abs(held["value"] - 2_000_000 * held["steps"] / held["seconds"]) / held["value"] < 1e-6
     assert 0 < held["launch_ms"] <= held["ms_per_step"] * 1.001
+    copy = roof["device_copy"]
+    assert copy["bytes"] == 48 * 2_000_000 and copy["unit"] == "GB/s"
+    assert abs(copy["achieved"] - copy["bytes"] / (copy["ms"] / 1e3) / 1e9) < 1e-6 * copy["achieved"]
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert cpu["unit"] == "particle-updates/s" and "particles" in cpu["sample"]
