@@ -11,13 +11,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace \
-    -- python3 "$REPO/bench.py" --steps "$STEPS" --warmup 10 --no-cpu-baseline \
+    -- python3 "$REPO/bench.py" --steps "$STEPS" --warmup 10 --no-cpu-baseline --sustained-seconds 0 --no-copy-yardstick \
     > "$OUT/trace_bench.json" 2> "$OUT/trace.err" || { echo "kernel-trace pass failed"; tail -5 "$OUT/trace.err"; exit 1; }
 echo "kernel-trace pass done"
 
 for C in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc \
-        -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline \
+        -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --sustained-seconds 0 --no-copy-yardstick \
         > "$OUT/pmc_${C}_bench.json" 2> "$OUT/pmc_$C.err" || { echo "pmc pass $C failed"; tail -5 "$OUT/pmc_$C.err"; exit 1; }
     echo "pmc pass $C done"
 done
