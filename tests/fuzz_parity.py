@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 psim = importlib.import_module("particle-simulation-3d_amd")
 import psim_testlib as T  # noqa: E402
 import random_cases  # noqa: E402
