@@ -159,3 +159,23 @@ def replay(inputs, ui):
             if abs(aspect - cam.aspect) > F(0.001):
                 cam.aspect = aspect
     return np.array(out, dtype=PARAMS_DTYPE) if out else np.zeros(0, PARAMS_DTYPE)
+
+
+def frame_stats(delta_times, paused, update_ms):
+    """The two numbers of the application's statistics panel after every frame (reference:
+    src/app.rs:209-216 frames per second over at least one second, counted on every frame;
+    src/app.rs:309-315 the host time of the update call smoothed with alpha = 0.1, only on
+    frames that updated; initial values src/app.rs:151-155) -> float32 array [frames, 2]."""
+    fps, counter, timer, smoothed = F(0), 0, F(0), F(0)
+    alpha = F(0.1)
+    out = np.zeros((len(delta_times), 2), dtype=np.float32)
+    for k, (dt, p, ms) in enumerate(zip(delta_times, paused, update_ms)):
+        counter += 1
+        timer = timer + F(dt)
+        if timer >= F(1.0):
+            fps = F(counter) / timer
+            counter, timer = 0, F(0)
+        if not p:
+            smoothed = (F(1.0) - alpha) * smoothed + alpha * F(ms)
+        out[k] = (fps, smoothed)
+    return out

@@ -9,6 +9,7 @@
 // state takes a detour through a checkpoint file.
 //
 // usage: frame_loop <count> <generation 0|1|2> <frames> <params_out> <particles_out>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,7 @@
 #include <vector>
 
 #include "psim.hpp"
+#include "psim_caller.hpp"
 
 int main(int argc, char **argv)
 {
@@ -35,11 +37,13 @@ int main(int argc, char **argv)
         float attractor[3] = {0.0f, 0.0f, 48.0f};
         uint32_t color_mode = 0;
         std::vector<psim::SimParams> used;
+        psim::FrameStats stats;                                // app.rs:209-216, 303-315
 
         for (int frame = 0; frame < frames; ++frame) {
             // a frame-time pattern standing in for the wall clock (app.rs:204-207)
             const float frame_ms[4] = {16.0f, 17.5f, 15.25f, 33.0f};
             const float delta_time = frame_ms[frame % 4] / 1000.0f;
+            stats.frame(delta_time);
 
             // scripted "user": drags the attractor on a square path, toggles things
             const bool dragging = (frame / 8) % 4 != 3;
@@ -83,7 +87,10 @@ int main(int argc, char **argv)
                 p.is_mouse_dragging = dragging ? 1u : 0u;
                 p.damping = 0.99f;
                 p.max_dist_for_color = max_dist;
+                const auto update_start = std::chrono::steady_clock::now();   // app.rs:303
                 sim.update(p);                                 // app.rs:306-307
+                stats.update_took(std::chrono::duration<float, std::milli>(
+                                      std::chrono::steady_clock::now() - update_start).count());
                 used.push_back(p);
             }
         }
@@ -105,6 +112,8 @@ int main(int argc, char **argv)
         std::fwrite(out.data(), sizeof(psim::Particle), out.size(), f);
         std::fclose(f);
         std::printf("frames=%d updates=%zu particles=%zu\n", frames, used.size(), out.size());
+        // what the reference's statistics panel would show (app.rs:325-330)
+        std::printf("fps=%.1f update_time_ms=%.4f\n", stats.fps, stats.simulation_update_time);
     } catch (const psim::Error &e) {
         std::fprintf(stderr, "psim error %d: %s\n", e.code(), e.what());
         return 1;

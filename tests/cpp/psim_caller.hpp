@@ -7,6 +7,8 @@
 //     attractor depth along the view direction            (reference: src/app.rs:528-576)
 //   * keyboard camera motion, projection of the cursor onto the plane through the
 //     attractor that faces the camera, SimParams assembly (reference: src/app.rs:202-301)
+//   * the two figures the application shows about itself: frames per second and the smoothed
+//     host time of the update call                        (reference: src/app.rs:209-216, 303-315)
 //
 // All arithmetic is fp32 in the reference's operation order (glam Vec3: dot =
 // (x*x' + y*y') + z*z', normalize = v * (1 / length), cross as written below); compile
@@ -176,6 +178,35 @@ struct CallerState {
         const float aspect_ratio = in.screen_width / in.screen_height;
         if (std::fabs(aspect_ratio - camera.aspect) > 0.001f) camera.aspect = aspect_ratio;
         return p;
+    }
+};
+
+// The statistics panel's two numbers (app.rs:325-330; initial values app.rs:151-155).
+struct FrameStats {
+    float fps = 0.0f;
+    uint32_t fps_counter = 0;
+    float fps_timer = 0.0f;
+    float simulation_update_time = 0.0f;   // milliseconds, exponentially smoothed
+
+    // Every frame, paused or not (app.rs:209-216): frames over at least one second.
+    void frame(float delta_time)
+    {
+        fps_counter += 1;
+        fps_timer += delta_time;
+        if (fps_timer >= 1.0f) {
+            fps = static_cast<float>(fps_counter) / fps_timer;
+            fps_counter = 0;
+            fps_timer = 0.0f;
+        }
+    }
+
+    // After an update call that took `update_time_ms` of host time (app.rs:309-315).  For an
+    // asynchronous backend that is the time to enqueue the step, as for the reference's
+    // compute backend; psim_timer_start / psim_timer_stop give the device's time instead.
+    void update_took(float update_time_ms)
+    {
+        const float ALPHA = 0.1f;
+        simulation_update_time = (1.0f - ALPHA) * simulation_update_time + ALPHA * update_time_ms;
     }
 };
 

@@ -2,7 +2,7 @@
 // (tests/cpp/psim_caller.hpp; reference: src/app.rs:202-301, 528-576) and, when built with
 // PSIM_WITH_DEVICE, feeds the resulting SimParams stream to the simulation.
 //
-//   caller_params  <inputs> <ui> <params_out>                      (no GPU, links nothing)
+//   caller_params  <inputs> <ui> <params_out> [<update_ms> <stats_out>]  (no GPU, links nothing)
 //   session_replay <inputs> <ui> <params_out> <count> <generation> <particles_out> [batch]
 //
 // <inputs>: psim::FrameInput records (48 B each).  <ui>: one UiFrame per frame -- the
@@ -10,6 +10,9 @@
 // <params_out>: the SimParams of every frame that was not paused, in order.
 // With "batch" the whole stream goes through update_batch() instead of one update() per
 // frame; the particles must come out the same.
+// <update_ms>: one float per frame, the host time the update call of that frame took (a
+// recorded stand-in for the wall clock of app.rs:303-309); <stats_out> then receives, per
+// frame, the two numbers of the statistics panel: {fps, smoothed update time}.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,8 +58,8 @@ int main(int argc, char **argv)
         return 2;
     }
 #else
-    if (argc != 4) {
-        std::fprintf(stderr, "usage: %s inputs ui params_out\n", argv[0]);
+    if (argc != 4 && argc != 6) {
+        std::fprintf(stderr, "usage: %s inputs ui params_out [update_ms stats_out]\n", argv[0]);
         return 2;
     }
 #endif
@@ -71,6 +74,14 @@ int main(int argc, char **argv)
     if (!inputs.empty())                       // the window's aspect at start-up (camera.rs:40, app.rs:100)
         app.camera.aspect = inputs[0].screen_width / inputs[0].screen_height;
     std::vector<psim_sim_params> used;
+    std::vector<float> update_ms, shown;
+#ifndef PSIM_WITH_DEVICE
+    if (argc == 6 && (!read_records(argv[4], update_ms) || update_ms.size() != inputs.size())) {
+        std::fprintf(stderr, "update_ms must hold one float per frame\n");
+        return 4;
+    }
+#endif
+    psim::FrameStats stats;
     for (size_t i = 0; i < inputs.size(); ++i) {
         app.gravity = ui[i].gravity;
         app.mouse_force = ui[i].mouse_force;
@@ -79,8 +90,17 @@ int main(int argc, char **argv)
         app.color_mode = ui[i].color_mode;
         const psim_sim_params p = app.frame(inputs[i]);
         if (!ui[i].paused) used.push_back(p);  // app.rs:283: a paused frame still moves the camera and the attractor
+        if (!update_ms.empty()) {
+            stats.frame(inputs[i].delta_time);                       // app.rs:209-216: every frame
+            if (!ui[i].paused) stats.update_took(update_ms[i]);      // app.rs:309-315: frames that updated
+            shown.push_back(stats.fps);
+            shown.push_back(stats.simulation_update_time);
+        }
     }
     if (!write_records(argv[3], used)) return 4;
+#ifndef PSIM_WITH_DEVICE
+    if (argc == 6 && !write_records(argv[5], shown)) return 4;
+#endif
 
 #ifdef PSIM_WITH_DEVICE
     const uint32_t count = static_cast<uint32_t>(std::strtoul(argv[4], nullptr, 10));

@@ -124,6 +124,34 @@ def test_projection_by_hand(tmp_path):
     assert np.allclose(p["mouse_position"], (0.0, 0.0, 48.0), atol=1e-4)
 
 
+def test_statistics_panel_numbers(tmp_path):
+    """Frames per second (over at least one second, counted on every frame) and the smoothed
+    host time of the update call (only frames that updated): src/app.rs:209-216, 303-315,
+    shown at app.rs:325-330.  The C++ mirror against the numpy restatement, bit for bit, and
+    the first values by hand."""
+    build()
+    inputs, ui = synthetic_session(360, seed=5)
+    rng = np.random.default_rng(5)
+    update_ms = rng.uniform(0.004, 0.4, len(inputs)).astype(np.float32)
+    fi, fu, fo, fm, fs = (str(tmp_path / n) for n in ("i.bin", "u.bin", "p.bin", "ms.bin", "s.bin"))
+    inputs.tofile(fi)
+    ui.tofile(fu)
+    update_ms.tofile(fm)
+    r = subprocess.run([CALLER, fi, fu, fo, fm, fs], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(fs, dtype=np.float32).reshape(-1, 2)
+    want = C.frame_stats(inputs["delta_time"], ui["paused"], update_ms)
+    assert got.shape == want.shape == (360, 2) and got.tobytes() == want.tobytes()
+    # by hand: no rate before a second has passed, then frames / seconds of that window
+    elapsed = np.cumsum(inputs["delta_time"].astype(np.float64))
+    first = int(np.argmax(elapsed >= 1.0 - 1e-6))
+    assert (got[:first - 1, 0] == 0).all() and got[first + 1, 0] > 0
+    assert abs(got[first + 1, 0] - (first + 1) / elapsed[first]) < 1.0
+    # the smoothed time starts from 0 with alpha = 0.1 and stands still while paused
+    assert got[0, 1] == np.float32(0.1) * update_ms[0]
+    assert (got[100:108, 1] == got[99, 1]).all() and got[108, 1] != got[107, 1]
+
+
 def test_empty_session(tmp_path):
     got = run_caller(tmp_path, np.zeros(0, C.INPUT_DTYPE), np.zeros(0, C.UI_DTYPE))
     assert len(got) == 0 and len(C.replay(np.zeros(0, C.INPUT_DTYPE), np.zeros(0, C.UI_DTYPE))) == 0

@@ -44,6 +44,10 @@ def test_frame_loop_matches_oracle_replay(tmp_path, count, generation):
     r = subprocess.run([BINARY, str(count), str(generation), str(frames), pfile, qfile],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
+    # the statistics panel's numbers (app.rs:325-330): 72 frames of ~20 ms pass one second
+    # once, and the update call of an asynchronous backend returns in well under a frame
+    shown = dict(kv.split("=") for kv in r.stdout.splitlines()[-1].split())
+    assert 40.0 < float(shown["fps"]) < 70.0 and 0.0 < float(shown["update_time_ms"]) < 16.0
     raw = np.fromfile(pfile, dtype=np.uint8).reshape(-1, 48)
     assert len(raw) == frames - 4                      # frames 44..47 were paused
     got = np.fromfile(qfile, dtype=psim.PARTICLE_DTYPE)
