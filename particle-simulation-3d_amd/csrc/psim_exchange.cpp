@@ -256,6 +256,13 @@ PSIM_API int psim_exchange_unique_id(uint8_t id[PSIM_EXCHANGE_ID_BYTES])
     if (!id) return psim_fail(PSIM_ERR_INVALID, "null id");
     const Rccl *r = rccl();
     if (!r) return PSIM_ERR_COMM;
+    // RCCL answers a machine without a GPU with a "fatal error" banner on the process's
+    // output; say it here instead.
+    int devices = 0;
+    if (hipGetDeviceCount(&devices) != hipSuccess || devices <= 0) {
+        (void)hipGetLastError();
+        return psim_fail(PSIM_ERR_COMM, "no HIP device visible: RCCL cannot make a communicator id");
+    }
     ncclUniqueId u;
     RCCL_TRY(r, r->GetUniqueId(&u));
     memcpy(id, u.internal, PSIM_EXCHANGE_ID_BYTES);
