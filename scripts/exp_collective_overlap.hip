@@ -17,9 +17,10 @@
 // starts when the update kernel ends, whatever its stream's priority; with 8-32 CUs masked out
 // of the update kernel's stream it runs under the kernel, and the 6.25 M-particle step does not
 // slow down (the 100 M-particle step would, by 2.7 %).  The library does NOT mask its streams
-// all the same: tearing down a CU-masked stream that has carried large device-to-host copies
-// left the runtime hanging in a later hipStreamDestroy or at process exit in about one run of
-// three, and whether the real collective behaves like the stand-in needs several GPUs to see.
+// all the same: of six short programs that carried large device-to-host copies on a CU-masked
+// stream and then destroyed it, three left the runtime hanging in a later hipStreamDestroy or at
+// process exit (none of seven that ran only kernels and small copies on it did), and whether
+// the real collective behaves like the stand-in needs several GPUs to see.
 // A caller who wants to try hands the handle a masked stream of its own (psim_set_stream).
 //
 // build (from the repository root):
