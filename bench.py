@@ -81,9 +81,10 @@ def parse_args():
                     help="particles stepped by the CPU baseline (default: the GPU's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sustained-seconds", type=float, default=6.0,
+    ap.add_argument("--sustained-seconds", type=float, default=None,
                     help="after the timed steps, keep stepping for about this long and report "
-                         "the rate held (`sustained`; 0: leave it out)")
+                         "the rate held (`sustained`; 0: leave it out; default 6, and 0 in a "
+                         "rehearsal of several ranks on one GPU)")
     ap.add_argument("--no-exchange-check", action="store_true")
     ap.add_argument("--no-copy-yardstick", action="store_true",
                     help="leave out roofline.device_copy (the runtime's device-to-device copy of "
@@ -424,8 +425,14 @@ def main():
     # steps take milliseconds; this says what the device holds once clocks and temperature
     # have settled (and keeps the GPU busy long enough for an outside sampler to see it).
     sustained = None
-    if args.sustained_seconds > 0 and not rehearsal:
-        k = int(args.sustained_seconds * 1e3 / max(device_ms / args.steps, 1e-4))
+    hold_seconds = args.sustained_seconds
+    if hold_seconds is None:
+        hold_seconds = 0.0 if rehearsal else 6.0
+    if hold_seconds > 0:
+        # The number of steps comes from `elapsed`, which is the same on every rank after the
+        # reduction above: with one attractor per rank a step is a collective, and ranks that
+        # took different numbers of steps would wait for each other for ever.
+        k = int(hold_seconds / max(elapsed / args.steps, 1e-7))
         k = max(args.steps, min(k, 1_000_000))
         t1 = time.perf_counter()
         sim.timer_start()
@@ -437,7 +444,7 @@ def main():
         held_s = time.perf_counter() - t1
         slowest = [held_s, held_ms]
         if distributed:
-            t = torch.tensor(slowest, dtype=torch.float64, device="cuda")
+            t = torch.tensor(slowest, dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             slowest = [float(v) for v in t.tolist()]
         sustained = {"steps": k, "seconds": slowest[0], "ms_per_step": slowest[0] / k * 1e3,

@@ -227,6 +227,19 @@ def test_config_5_two_rank_rehearsal():
         assert abs(out["value"] - 1_000_000 * 40 / (out["ms_per_step"] * 40e-3)) / out["value"] < 1e-6
 
 
+def test_config_5_two_ranks_hold_the_step_for_the_same_number_of_steps():
+    """The step held after the timed steps (`sustained`) on several ranks of --config 5, where
+    every step is a collective: all ranks must take the same number of steps -- derived from
+    the reduced time, not from each rank's own -- or they would wait for each other for ever."""
+    r, lines = launch_ranks(2, "--config", "5", "--steps", "20", "--warmup", "5", "--particles",
+                            "500000", "--sustained-seconds", "0.4", port=29599)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[:1000]
+    held = json.loads(lines[0])["sustained"]
+    assert held["steps"] >= 20 and 0.05 < held["seconds"] < 30.0
+    assert abs(held["value"] - 1_000_000 * held["steps"] / held["seconds"]) / held["value"] < 1e-6
+
+
 # ---- readiness for a multi-GPU node: worlds of 4 and 8 rehearsed on this machine's GPU --------
 
 def launch_ranks(world, *args, port, env_extra=None, timeout=280):
