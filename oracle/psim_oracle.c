@@ -9,8 +9,11 @@
  * here: no rustc/cargo) and ships no tests, golden vectors or fixtures for this
  * path.  The restatement is pinned instead by (1) an independent op-by-op
  * numpy-float32 derivation (tests/gen_golden.py), compared on committed vectors
- * and on seeded random sweeps (tests/test_random_parity.py), and (2) hand-derived
- * known answers (tests/test_oracle_golden.py).
+ * and on seeded random sweeps (tests/test_random_parity.py), (2) hand-derived
+ * known answers (tests/test_oracle_golden.py), and (3) the reference's own second
+ * implementation, the compute shader (src/shaders/compute.wgsl:31-99), restated
+ * from its text and required to agree to 1e-5 wherever the two sources say the
+ * same thing (tests/test_wgsl_twin.py) -- which pins the algorithm, not the bits.
  *
  * What is restated (paths relative to the reference root):
  *   src/simulation/cpu.rs:51-59    parameter hoist, dragging = is_mouse_dragging > 0
