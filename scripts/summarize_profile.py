@@ -88,6 +88,9 @@ def main():
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
         f.write(f"# {tag}: `python bench.py --steps {bench['steps']} --warmup {bench['warmup']}` "
                 f"under rocprofv3 (MI355X, {n} particles)\n\n")
+        f.write("The profiled command stops after the timed steps (`--no-cpu-baseline "
+                "--sustained-seconds 0 --no-copy-yardstick`), so every traced launch of the update "
+                "kernel is a warm-up or a timed step.\n\n")
         f.write("| quantity | value |\n|---|---|\n")
         f.write(f"| update kernel launches traced | {summary['launches_traced']} |\n")
         f.write(f"| rocprofv3 average launch duration | {avg_ms:.4f} ms |\n")
