@@ -73,9 +73,13 @@ def parse_args():
     ap.add_argument("--workload", choices=["single", "multi"], default=None,
                     help="single: one attractor, no communication; multi: one moving attractor "
                          "per rank, all-gathered every step (default: what --config says)")
-    ap.add_argument("--pacing", choices=["host", "device"], default="host",
+    ap.add_argument("--pacing", choices=["host", "device"], default=None,
                     help="multi workload: who waits for a step's all-gather, the calling thread "
-                         "(kernels then run back to back) or the kernel's stream (see "
+                         "(kernels then run back to back: the default on one rank, where it is "
+                         "3 us per step faster) or the kernel's stream (the default on several "
+                         "ranks: the host runs ahead, so every all-gather is already waiting when "
+                         "the previous kernel's grid runs dry, which is the one moment a "
+                         "collective's workgroup finds room beside the update kernel; see "
                          "psim_exchange_set_pacing)")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="particles stepped by the CPU baseline (default: the GPU's count)")
@@ -331,6 +335,8 @@ def main():
     config_name, per_gpu, fixed_total, workload = CONFIGS[args.config]
     if args.workload:
         workload = args.workload
+    if args.pacing is None:
+        args.pacing = "host" if world == 1 else "device"
     # PSIM_BENCH_REHEARSAL=1 (tests only): several ranks share the GPUs that exist and talk
     # over gloo, so the N > 1 control flow can be run on a one-GPU machine.  The numbers of
     # such a run mean nothing.

@@ -14,9 +14,11 @@
 // stream with a CU mask), which gives the stand-in a place to run?
 //
 // What it showed (profiles/tuning/r03_collective_overlap.log): without free CUs the stand-in
-// starts when the update kernel ends, whatever its stream's priority; with 8-32 CUs masked out
-// of the update kernel's stream it runs under the kernel, and the 6.25 M-particle step does not
-// slow down (the 100 M-particle step would, by 2.7 %).  The library does NOT mask its streams
+// starts when the update kernel ends, whatever its stream's priority -- or at the boundary
+// between two launches when the step is issued in two halves; with 8-32 CUs masked out of the
+// update kernel's stream it runs under the kernel, and the 6.25 M-particle step does not slow
+// down (the 100 M-particle step would, by 2.7 %).  So a collective must already be waiting when
+// a kernel's grid runs dry: the exchange's device pacing, where the host runs ahead, does that.  The library does NOT mask its streams
 // all the same: of six short programs that carried large device-to-host copies on a CU-masked
 // stream and then destroyed it, three left the runtime hanging in a later hipStreamDestroy or at
 // process exit (none of seven that ran only kernels and small copies on it did), and whether
@@ -145,7 +147,11 @@ int main()
 
     const Shape shapes[] = {{"6.25 M particles, 8 attractors (one GPU's share of the 50 M configuration)", 6250000u, 8u},
                             {"100 M particles, single attractor (the headline; no collective runs beside it)", 100000000u, 1u}};
-    const int free_cus[] = {0, -1, 8, 16, 32};      // -1: no mask, the stand-in's stream at the highest priority
+    // -1: no mask, the stand-in's stream at the highest priority; -3 / -2: no mask, the step as
+    // one launch / as two launches over the halves of the arrays (the stateless single-attractor
+    // entry point on the handle's arrays): does the boundary between two launches, where the
+    // first one's grid runs dry, give the stand-in its place?
+    const int free_cus[] = {0, -1, -3, -2, 8, 16, 32};
     for (const Shape &shape : shapes) {
         printf("\n%s\n", shape.name);
         printf("%-28s %12s %14s %16s %16s %14s\n", "update kernel's stream", "us per step",
@@ -155,7 +161,7 @@ int main()
         for (int leave : free_cus) {
             hipStream_t stream = nullptr;
             if (side) TRY(hipStreamDestroy(side));
-            if (leave < 0) TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
+            if (leave == -1) TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
             else TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
             if (leave <= 0) {
                 TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -167,7 +173,21 @@ int main()
                 TRY(hipExtStreamCreateWithCUMask(&stream, (uint32_t)((cus + 31) / 32), mask));
             }
             PSIM_TRY(psim_set_stream(h, stream));
+            psim_soa_view v;
+            PSIM_TRY(psim_device_soa(h, &v));
+            const uint32_t half = (shape.particles / 2u) & ~1023u;
             const auto update = [&]() {
+                if (leave == -3)
+                    return psim_update_soa(v.px, v.py, v.pz, v.vx, v.vy, v.vz, nullptr, shape.particles,
+                                           &params, stream);
+                if (leave == -2) {
+                    const int rc = psim_update_soa(v.px, v.py, v.pz, v.vx, v.vy, v.vz, nullptr, half,
+                                                   &params, stream);
+                    if (rc != PSIM_OK) return rc;
+                    return psim_update_soa(v.px + half, v.py + half, v.pz + half, v.vx + half,
+                                           v.vy + half, v.vz + half, nullptr, shape.particles - half,
+                                           &params, stream);
+                }
                 return shape.attractors == 1 ? psim_update(h, &params)
                                              : psim_update_multi_host(h, &params, list, shape.attractors);
             };
@@ -203,7 +223,9 @@ int main()
                 kernel.push_back((double)(stamps[1] - stamps[0]) / 100.0);
             }
             char label[64], xcds[128] = "";
-            if (leave < 0) snprintf(label, sizeof(label), "no mask, stand-in high prio");
+            if (leave == -3) snprintf(label, sizeof(label), "no mask, 1 attr., 1 launch");
+            else if (leave == -2) snprintf(label, sizeof(label), "no mask, 1 attr., 2 launches");
+            else if (leave < 0) snprintf(label, sizeof(label), "no mask, stand-in high prio");
             else snprintf(label, sizeof(label), leave ? "mask leaves %d CUs free" : "no mask", leave);
             for (int x = 0; x < 8; ++x) snprintf(xcds + strlen(xcds), sizeof(xcds) - strlen(xcds), "%s%d", x ? "+" : "", per_xcd[x]);
             printf("%-28s %12.2f %14s %13.1f us %13.1f us %11.1f us\n", label, 1e3 * ms / steps, xcds,
