@@ -241,7 +241,9 @@ impl ShardedRank {
     }
 
     /// A headless rank has nothing else to do between frames: let the thread wait for each
-    /// gather, so that the kernels run back to back (`PSIM_EXCHANGE_HOST_PACED`).
+    /// gather, so that the kernels run back to back (`PSIM_EXCHANGE_HOST_PACED`).  Faster on one
+    /// rank; on several GPUs measure first: the default pacing keeps the gathers a step ahead,
+    /// which is what lets them find room beside the kernels.
     pub fn pace_from_host(&mut self) {
         check(unsafe { psim_exchange_set_pacing(self.exchange, PSIM_EXCHANGE_HOST_PACED) });
     }
