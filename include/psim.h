@@ -571,7 +571,12 @@ int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
  * previous step's kernel -- and then enqueues the kernel with nothing in front of it, so kernels
  * run back to back; the call returns once the gather has finished (the kernel still runs
  * asynchronously).  Pays when a step's kernel takes longer than the gather plus the host's
- * work, i.e. for shards of millions of particles.  All ranks may choose independently. */
+ * work, i.e. for shards of millions of particles -- measured on one rank, where no collective
+ * kernel runs.  On several GPUs the collective's workgroup (RCCL's wants most of a CU) only
+ * finds room at the moment an update kernel's grid runs dry; device pacing, with the host
+ * running ahead, has the next gather waiting at that moment, host pacing enqueues it about
+ * when the next kernel starts.  Measure both before switching.  All ranks may choose
+ * independently. */
 enum {
     PSIM_EXCHANGE_DEVICE_PACED = 0,
     PSIM_EXCHANGE_HOST_PACED   = 1
