@@ -116,6 +116,18 @@ bool wait_for(const std::atomic<uint32_t> &v, uint32_t at_least, int seconds,
     return true;
 }
 
+// How long the helper thread spins for its kernel before it starts napping (a nap costs tens of
+// microseconds of latency: fine for the tests, too slow for timing rehearsals, which raise it
+// with PSIM_FAKE_RCCL_SPIN).
+uint32_t patience()
+{
+    static const uint32_t spins = [] {
+        const char *e = getenv("PSIM_FAKE_RCCL_SPIN");
+        return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : 2000u;
+    }();
+    return spins;
+}
+
 uint32_t load_acquire(const uint32_t *p)
 {
     return __atomic_load_n(p, __ATOMIC_ACQUIRE);
@@ -133,7 +145,7 @@ void carry(Comm *c)
         const uint32_t ticket = (uint32_t)(seq + 1);
         for (uint32_t spins = 0; load_acquire(&mb->sent[slot]) != ticket; ++spins) {
             if (c->stop.load(std::memory_order_acquire)) return;
-            if (spins > 2000) nap();
+            if (spins > patience()) nap();
         }
         const uint32_t words = c->words;
         TRACE("rank %d: collective %llu has left the device", c->rank, (unsigned long long)seq);
@@ -183,6 +195,52 @@ __global__ void __launch_bounds__(64) gather_kernel(const uint32_t *send, uint32
         for (uint32_t i = lane; i < world * words; i += 64) recv[i] = mb->in[slot][i];
 }
 
+// The same collective with the resource footprint of RCCL's own device kernel on gfx950
+// (ncclDevKernel_Generic_*: 37 664 B of LDS, 248 vector registers per lane, 512 threads), for
+// rehearsing WHEN such a workgroup finds room beside the update kernel.  Wave 0 does the work
+// of gather_kernel, the other seven only take their place.  PSIM_FAKE_RCCL_FAT=1 selects it.
+__global__ void __launch_bounds__(512) gather_kernel_fat(const uint32_t *send, uint32_t *recv,
+                                                         Mailbox *mb, int slot, uint32_t ticket,
+                                                         uint32_t words, uint32_t world)
+{
+    __shared__ char ballast[37664 - 16];
+    __shared__ uint32_t released;
+    const uint32_t lane = threadIdx.x;
+    ballast[lane] = (char)lane;
+    asm volatile("" ::: "v247");
+    if (lane < words) mb->out[slot][lane] = send[lane];
+    __threadfence_system();
+    if (lane == 0) {
+        __hip_atomic_store(&mb->sent[slot], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t start = wall_clock64();
+        uint32_t ok = 0;
+        for (uint32_t spins = 0; spins < kDeviceSpins; ++spins) {
+            if (__hip_atomic_load(&mb->done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == ticket) {
+                ok = 1;
+                break;
+            }
+            if (__hip_atomic_load(&mb->abort, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+            if (wall_clock64() - start > kDeviceTicks) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        if (!ok) __hip_atomic_store(&mb->gave_up, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        released = ok + (uint32_t)(ballast[5] == 77);
+    }
+    __syncthreads();
+    __threadfence_system();
+    if (released && lane < 64)
+        for (uint32_t i = lane; i < world * words; i += 64) recv[i] = mb->in[slot][i];
+}
+
+bool fat()
+{
+    static const bool on = [] {
+        const char *e = getenv("PSIM_FAKE_RCCL_FAT");
+        return e && *e == '1';
+    }();
+    return on;
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,6 +285,8 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t 
     c->shared = static_cast<Shared *>(p);
     // The kernel's code is loaded, and has run once, before any rank can be waiting in it.
     hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(64), 0, nullptr, nullptr, nullptr, c->box, 0, 0u, 0u, 0u);
+    if (fat())
+        hipLaunchKernelGGL(gather_kernel_fat, dim3(1), dim3(512), 0, nullptr, nullptr, nullptr, c->box, 0, 0u, 0u, 0u);
     if (hipDeviceSynchronize() != hipSuccess) return ncclUnhandledCudaError;
     TRACE("rank %d of %d joins %s", rank, nranks, c->name);
     c->shared->joined.fetch_add(1, std::memory_order_acq_rel);
@@ -290,9 +350,14 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void *se
     if (c->words != (uint32_t)count) return ncclInvalidArgument;   // one shape per communicator
     const uint64_t seq = c->seq++;
     TRACE("rank %d: collective %llu enqueued", c->rank, (unsigned long long)seq);
-    hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(64), 0, stream,
-                       static_cast<const uint32_t *>(send), static_cast<uint32_t *>(recv), c->box,
-                       (int)(seq % kSlots), (uint32_t)(seq + 1), (uint32_t)count, (uint32_t)c->world);
+    if (fat())
+        hipLaunchKernelGGL(gather_kernel_fat, dim3(1), dim3(512), 0, stream,
+                           static_cast<const uint32_t *>(send), static_cast<uint32_t *>(recv), c->box,
+                           (int)(seq % kSlots), (uint32_t)(seq + 1), (uint32_t)count, (uint32_t)c->world);
+    else
+        hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(64), 0, stream,
+                           static_cast<const uint32_t *>(send), static_cast<uint32_t *>(recv), c->box,
+                           (int)(seq % kSlots), (uint32_t)(seq + 1), (uint32_t)count, (uint32_t)c->world);
     return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 
