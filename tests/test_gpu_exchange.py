@@ -94,12 +94,13 @@ def build_c_hosts():
     return cpp_dir
 
 
-def start_ranks(tmp_path, world, n, steps, pacing, extra=lambda rank: ()):
+def start_ranks(tmp_path, world, n, steps, pacing, extra=lambda rank: (), env_extra=None):
     """`world` C host processes (tests/cpp/exchange_loop) sharing GPU 0, the exchange pointed at
     the test double; rank 0 is started last, so the others really wait for its rendezvous file.
     Returns {rank: process}."""
     cpp_dir = build_c_hosts()
     env = dict(os.environ, PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"))
+    env.update(env_extra or {})
     return {r: subprocess.Popen([os.path.join(cpp_dir, "exchange_loop"), str(r), str(world), "0",
                                  str(n), str(steps), str(tmp_path / "id"), pacing, *extra(r)],
                                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -144,6 +145,23 @@ def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world, pacing,
     n, steps = 50_003, 20                                # 40 steps in all: the ring goes round
     extra = (lambda r: (f"timeout_ms={timeout_ms}",)) if timeout_ms else (lambda r: ())
     outs = checksums_of(start_ranks(tmp_path, world, n, steps, pacing, extra))
+    params = T.make_params(**C_HOST_PARAMS)
+    for r in range(world):
+        want = T.oracle_gen_uniform_aos(r * n, n)
+        for t in range(2 * steps):
+            want = T.oracle_update_aos(want, params, 1, c_host_attractors(world, t))
+        assert outs[r] == T.oracle_checksum_soa(T.aos_to_soa(want)), f"rank {r} of {world}"
+
+
+@pytest.mark.parametrize("pacing", ["host", "device"])
+def test_an_all_gather_kernel_as_large_as_rccls_changes_no_result(tmp_path, pacing):
+    """The test double with its all-gather kernel given the resource footprint of RCCL's own
+    device kernel (37 664 B of LDS, 248 vector registers, 512 threads: a workgroup that waits
+    for most of a CU, which the update kernels only yield when their grid runs dry): two ranks
+    sharing the GPU still deliver the oracle's particles, whoever waits for whom."""
+    world, n, steps = 2, 300_007, 12
+    outs = checksums_of(start_ranks(tmp_path, world, n, steps, pacing,
+                                    env_extra={"PSIM_FAKE_RCCL_FAT": "1"}))
     params = T.make_params(**C_HOST_PARAMS)
     for r in range(world):
         want = T.oracle_gen_uniform_aos(r * n, n)
