@@ -73,14 +73,14 @@ def parse_args():
     ap.add_argument("--workload", choices=["single", "multi"], default=None,
                     help="single: one attractor, no communication; multi: one moving attractor "
                          "per rank, all-gathered every step (default: what --config says)")
-    ap.add_argument("--pacing", choices=["host", "device"], default=None,
-                    help="multi workload: who waits for a step's all-gather, the calling thread "
-                         "(kernels then run back to back: the default on one rank, where it is "
-                         "3 us per step faster) or the kernel's stream (the default on several "
-                         "ranks: the host runs ahead, so every all-gather is already waiting when "
-                         "the previous kernel's grid runs dry, which is the one moment a "
-                         "collective's workgroup finds room beside the update kernel; see "
-                         "psim_exchange_set_pacing)")
+    ap.add_argument("--pacing", choices=["host", "device", "pipelined"], default=None,
+                    help="multi workload: who waits for a step's all-gather -- the calling thread "
+                         "(host: kernels run back to back; the default on one rank), the kernel's "
+                         "stream (device: the host runs ahead), or the calling thread one call late "
+                         "(pipelined, the default on several ranks: kernels back to back AND every "
+                         "all-gather already waiting when the previous kernel's grid runs dry, the "
+                         "one moment a collective's workgroup finds room beside the update kernel; "
+                         "see psim_exchange_set_pacing)")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="particles stepped by the CPU baseline (default: the GPU's count)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -285,7 +285,18 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
         runner.step()
     host_paced_ms = runner.sim.timer_stop()
     runner.finish()
-    last = 2 * (warmup + steps) - 1
+    # and one call late (kernels back to back, every gather enqueued ahead of the kernel before)
+    runner.exchange.set_pacing(psim.EXCHANGE_PIPELINED)
+    for _ in range(warmup):
+        runner.step()
+    runner.finish()
+    barrier()
+    runner.sim.timer_start()
+    for _ in range(steps):
+        runner.step()
+    pipelined_ms = runner.sim.timer_stop()
+    runner.finish()
+    last = 3 * (warmup + steps) - 1
     ok = runner.exchange.last_list().tobytes() == par.attractors_at(last, world).tobytes()
     # the same kernel without the exchange: the list handed over by the host
     table = par.attractors_at(last, world)
@@ -298,10 +309,10 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
     kernel_ms = runner.sim.timer_stop()
     runner.close()
     t = torch.tensor([wall / steps * 1e6, device_ms / steps * 1e3, kernel_ms / steps * 1e3,
-                      0.0 if ok else 1.0, host_paced_ms / steps * 1e3],
+                      0.0 if ok else 1.0, host_paced_ms / steps * 1e3, pipelined_ms / steps * 1e3],
                      dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    w, d, k, bad, hp = (float(v) for v in t.tolist())
+    w, d, k, bad, hp, pl = (float(v) for v in t.tolist())
     return {
         "workload": f"{n} particles per GPU, {world} moving attractors, psim_exchange_step "
                     f"(RCCL all-gather of 32 B per rank into a ring of receive lists) x {steps} steps",
@@ -309,6 +320,7 @@ def exchange_check(psim, par, torch, dist, rank, world, local_rank, params, step
         "us_per_step_wall": w,
         "us_per_step_device": d,
         "us_per_step_device_host_paced": hp,
+        "us_per_step_device_pipelined": pl,
         "us_per_step_kernel_only": k,
         "aggregation": "max over ranks",
     }
@@ -336,7 +348,7 @@ def main():
     if args.workload:
         workload = args.workload
     if args.pacing is None:
-        args.pacing = "host" if world == 1 else "device"
+        args.pacing = "host" if world == 1 else "pipelined"
     # PSIM_BENCH_REHEARSAL=1 (tests only): several ranks share the GPUs that exist and talk
     # over gloo, so the N > 1 control flow can be run on a one-GPU machine.  The numbers of
     # such a run mean nothing.

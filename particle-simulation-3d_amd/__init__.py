@@ -584,7 +584,7 @@ class HipParticleGroup:
 
 
 EXCHANGE_ID_BYTES = 128
-EXCHANGE_DEVICE_PACED, EXCHANGE_HOST_PACED = 0, 1
+EXCHANGE_DEVICE_PACED, EXCHANGE_HOST_PACED, EXCHANGE_PIPELINED = 0, 1, 2
 
 
 def exchange_unique_id():
@@ -633,7 +633,8 @@ class HipAttractorExchange:
             _check(rc)
 
     def set_pacing(self, pacing):
-        """EXCHANGE_DEVICE_PACED (default) or EXCHANGE_HOST_PACED: see include/psim.h."""
+        """EXCHANGE_DEVICE_PACED (default), EXCHANGE_HOST_PACED or EXCHANGE_PIPELINED (the
+        handle is then one step behind until sync()): see include/psim.h."""
         _check(self._lib.psim_exchange_set_pacing(self._x, int(pacing)))
 
     def set_timeout(self, timeout_ms):

@@ -19,7 +19,12 @@
 // with the ring the record is needed once per 8 steps.  The wait goes too when the exchange
 // is host-paced (psim_exchange_set_pacing): the calling thread waits for the gather, which has
 // run under the previous kernel, and the kernel is enqueued directly behind its predecessor
-// (44.7 us per step against 47.5 device-paced and 42.3 for the bare kernel).
+// (44.7 us per step against 47.5 device-paced and 42.3 for the bare kernel).  That holds while
+// the gather finds room beside a running kernel, which a collective as large as RCCL's device
+// kernel does not (it starts when the kernel's grid runs dry: scripts/exp_collective_overlap.hip).
+// Pipelined pacing is host pacing one call late: a call enqueues its gather FIRST, then waits
+// for the previous step's gather and enqueues the previous step's kernel, so kernels still run
+// back to back and every gather is already waiting when the kernel before it ends.
 //
 // The exchange moves 32 bytes per rank, so it is bound by latency, not by link bandwidth;
 // what matters is that nothing in a step waits on the host.  The reference has exactly one
@@ -151,7 +156,10 @@ struct psim_exchange {
     hipEvent_t gathered[16] = {};                     // per list: its all-gather has finished
     hipEvent_t kernel_done[2] = {nullptr, nullptr};   // per half: its last kernel has finished
     uint64_t t = 0;                                   // steps taken
-    bool host_paced = false;                          // see psim_exchange_set_pacing()
+    int pacing = PSIM_EXCHANGE_DEVICE_PACED;          // see psim_exchange_set_pacing()
+    bool pending = false;                             // pipelined: a step's kernel not yet enqueued
+    psim_sim_params pending_params = {};              //   its parameters
+    uint32_t pending_slot = 0;                        //   and the list its gather fills
     uint32_t timeout_ms = 0;                          // 0 = wait for ever, see psim_exchange_set_timeout()
     bool broken = false;                              // a step failed or timed out: unusable
     char why_broken[200] = "";
@@ -412,12 +420,38 @@ PSIM_API int psim_exchange_create(psim_exchange **out, psim_handle *h,
 
 namespace {
 
+// The kernel of the step whose all-gather fills list `slot`, behind that gather.  `wait`: how
+// the kernel is ordered behind the gather -- the handle's stream waits (device pacing), or the
+// calling thread does and the kernel goes in with nothing in front of it.
+int enqueue_kernel(psim_exchange *x, const psim_sim_params *params, uint32_t slot, bool host_waits)
+{
+    hipStream_t compute = static_cast<hipStream_t>(psim_get_stream(x->h));
+    psim_attractor *list = x->ring + (size_t)slot * (size_t)x->world;
+    if (host_waits) {
+        const int rc = wait_event(x, x->gathered[slot], "the all-gather of a step");
+        if (rc != PSIM_OK) return rc;
+    } else {
+        HIP_TRY(hipStreamWaitEvent(compute, x->gathered[slot], 0));
+    }
+    const int rc = psim_update_multi(x->h, params, list, (uint32_t)x->world);
+    if (rc != PSIM_OK) return rc;
+    if (slot % kHalf == kHalf - 1) HIP_TRY(hipEventRecord(x->kernel_done[slot / kHalf], compute));
+    return PSIM_OK;
+}
+
+// Pipelined pacing: the kernel that the previous call left for this one.
+int flush_pending(psim_exchange *x)
+{
+    if (!x->pending) return PSIM_OK;
+    x->pending = false;
+    return enqueue_kernel(x, &x->pending_params, x->pending_slot, true);
+}
+
 int step_impl(psim_exchange *x, const psim_sim_params *params, const psim_attractor *mine)
 {
     const Rccl *r = &g_rccl;                         // loaded: the exchange exists
     HIP_TRY(hipSetDevice(x->device));
     const uint32_t slot = (uint32_t)(x->t % kRing), half = slot / kHalf;
-    hipStream_t compute = static_cast<hipStream_t>(psim_get_stream(x->h));
     psim_attractor *list = x->ring + (size_t)slot * (size_t)x->world;
     // With a timeout the host never runs more than a ring ahead of the collectives: the gather
     // that used this list 16 steps ago must have finished, or the exchange is given up here --
@@ -433,17 +467,22 @@ int step_impl(psim_exchange *x, const psim_sim_params *params, const psim_attrac
     RCCL_TRY(r, r->AllGather(list + x->rank, list, kRecordWords, ncclInt32, x->comm,
                              x->comm_stream));       // in place: own record already sits at [rank]
     HIP_TRY(hipEventRecord(x->gathered[slot], x->comm_stream));
-    if (x->host_paced) {
-        // The HOST waits for the gather (which runs under the previous step's kernel), so the
-        // kernel goes into its queue with nothing in front of it but the previous kernel.
-        rc = wait_event(x, x->gathered[slot], "the all-gather of this step");
+    if (x->pacing == PSIM_EXCHANGE_PIPELINED) {
+        // This step's gather is in its queue; only now the PREVIOUS step's kernel goes in, behind
+        // a gather that has had a whole kernel to run under.  This step's kernel waits for the
+        // next call (or psim_exchange_sync).
+        rc = flush_pending(x);
         if (rc != PSIM_OK) return rc;
+        x->pending = true;
+        x->pending_params = *params;
+        x->pending_slot = slot;
     } else {
-        HIP_TRY(hipStreamWaitEvent(compute, x->gathered[slot], 0));
+        // Host-paced: the HOST waits for the gather (which runs under the previous step's
+        // kernel), so the kernel goes into its queue with nothing in front of it but the
+        // previous kernel.  Device-paced: the handle's stream waits.
+        rc = enqueue_kernel(x, params, slot, x->pacing == PSIM_EXCHANGE_HOST_PACED);
+        if (rc != PSIM_OK) return rc;
     }
-    rc = psim_update_multi(x->h, params, list, (uint32_t)x->world);
-    if (rc != PSIM_OK) return rc;
-    if (slot % kHalf == kHalf - 1) HIP_TRY(hipEventRecord(x->kernel_done[half], compute));
     ++x->t;
     return PSIM_OK;
 }
@@ -470,9 +509,21 @@ PSIM_API int psim_exchange_step(psim_exchange *x, const psim_sim_params *params,
 PSIM_API int psim_exchange_set_pacing(psim_exchange *x, int pacing)
 {
     if (!x) return psim_fail(PSIM_ERR_INVALID, "null exchange");
-    if (pacing != PSIM_EXCHANGE_DEVICE_PACED && pacing != PSIM_EXCHANGE_HOST_PACED)
+    if (pacing != PSIM_EXCHANGE_DEVICE_PACED && pacing != PSIM_EXCHANGE_HOST_PACED &&
+        pacing != PSIM_EXCHANGE_PIPELINED)
         return psim_fail(PSIM_ERR_INVALID, "unknown pacing %d", pacing);
-    x->host_paced = pacing == PSIM_EXCHANGE_HOST_PACED;
+    if (x->broken) return give_up(x, x->why_broken);
+    if (x->pending && pacing != PSIM_EXCHANGE_PIPELINED) {   // nothing stays behind in the old mode
+        HIP_TRY(hipSetDevice(x->device));
+        const int rc = flush_pending(x);
+        if (rc != PSIM_OK) {
+            char why[200];
+            snprintf(why, sizeof(why), "a step failed (%.150s)", psim_last_error());
+            if (!x->broken) (void)give_up(x, why);
+            return rc;
+        }
+    }
+    x->pacing = pacing;
     return PSIM_OK;
 }
 
@@ -488,7 +539,14 @@ PSIM_API int psim_exchange_sync(psim_exchange *x)
     if (!x) return psim_fail(PSIM_ERR_INVALID, "null exchange");
     HIP_TRY(hipSetDevice(x->device));
     if (x->broken) return give_up(x, x->why_broken);
-    int rc = wait_stream(x, x->comm_stream, "the communication stream");
+    int rc = flush_pending(x);                       // pipelined pacing: the last step's kernel
+    if (rc != PSIM_OK) {
+        char why[200];
+        snprintf(why, sizeof(why), "a step failed (%.150s)", psim_last_error());
+        if (!x->broken) (void)give_up(x, why);
+        return rc;
+    }
+    rc = wait_stream(x, x->comm_stream, "the communication stream");
     if (rc != PSIM_OK) return rc;
     if (x->timeout_ms == 0) return psim_sync(x->h);
     return wait_stream(x, static_cast<hipStream_t>(psim_get_stream(x->h)), "the handle's stream");

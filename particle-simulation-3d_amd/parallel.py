@@ -67,13 +67,16 @@ class NativeMultiAttractorRunner:
     lists, then the multi-attractor kernel).  `unique_id` is the 128-byte communicator id every rank received from the one that
     made it (HipParticleSimulation-side helpers: exchange_unique_id, exchange_rendezvous_file).
     Attractor `rank` follows the closed-form path of attractor_at().  `pacing` "host" makes
-    the calling thread wait for each gather so that the kernels run back to back (see
+    the calling thread wait for each gather so that the kernels run back to back, "pipelined"
+    does the same one call late, so that every gather is already waiting when the kernel before
+    it ends -- the particles are then one step behind until finish() (see
     psim_exchange_set_pacing in include/psim.h); `timeout_ms` > 0 bounds every wait of the
     exchange (psim_exchange_set_timeout)."""
 
     def __init__(self, particles_per_rank, rank, world, local_rank, params, unique_id,
                  force=5.0, radius=10.0, first=None, total=None, pacing="device", timeout_ms=0):
-        from . import HipAttractorExchange, EXCHANGE_DEVICE_PACED, EXCHANGE_HOST_PACED
+        from . import (HipAttractorExchange, EXCHANGE_DEVICE_PACED, EXCHANGE_HOST_PACED,
+                       EXCHANGE_PIPELINED)
         self.rank, self.world, self.params = rank, world, params
         self.force, self.radius = force, radius
         # this rank's shard [first, first + particles_per_rank) of `total` (default: equal shards)
@@ -82,8 +85,8 @@ class NativeMultiAttractorRunner:
             world * particles_per_rank if total is None else total,
             GEN_UNIFORM, device_id=local_rank)
         self.exchange = HipAttractorExchange(self.sim, unique_id, rank, world)
-        self.exchange.set_pacing({"device": EXCHANGE_DEVICE_PACED,
-                                  "host": EXCHANGE_HOST_PACED}[pacing])
+        self.exchange.set_pacing({"device": EXCHANGE_DEVICE_PACED, "host": EXCHANGE_HOST_PACED,
+                                  "pipelined": EXCHANGE_PIPELINED}[pacing])
         if timeout_ms:                 # give up (PsimError, code 6) instead of hanging on a lost rank
             self.exchange.set_timeout(timeout_ms)
         self.t = 0

@@ -248,6 +248,14 @@ impl ShardedRank {
         check(unsafe { psim_exchange_set_pacing(self.exchange, PSIM_EXCHANGE_HOST_PACED) });
     }
 
+    /// The pacing for a rank of a multi-GPU run that steps on and on: host pacing one call
+    /// late (`PSIM_EXCHANGE_PIPELINED`), so that kernels run back to back AND every all-gather
+    /// is already waiting when the kernel before it ends.  The particles are one step behind
+    /// until `sync`.
+    pub fn pace_pipelined(&mut self) {
+        check(unsafe { psim_exchange_set_pacing(self.exchange, PSIM_EXCHANGE_PIPELINED) });
+    }
+
     pub fn sync(&mut self) {
         check(unsafe { psim_exchange_sync(self.exchange) });
     }

@@ -130,6 +130,7 @@ pub const PSIM_RESIZE_REGENERATE: c_int = 0;
 pub const PSIM_RESIZE_APPEND: c_int = 1;
 pub const PSIM_EXCHANGE_DEVICE_PACED: c_int = 0;
 pub const PSIM_EXCHANGE_HOST_PACED: c_int = 1;
+pub const PSIM_EXCHANGE_PIPELINED: c_int = 2;
 
 #[link(name = "psim_hip")]
 extern "C" {

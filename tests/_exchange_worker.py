@@ -31,7 +31,7 @@ def one_rank_steps_equal_the_oracle(steps, pacing="device", switch_every=0, time
     try:
         for t in range(steps):
             if switch_every and t % switch_every == 0:   # the pacing may change between steps
-                runner.exchange.set_pacing((t // switch_every) % 2)
+                runner.exchange.set_pacing((t // switch_every) % 3)   # device, host, pipelined
             runner.step()
         runner.finish()
         got = runner.sim.download_aos()
@@ -123,12 +123,21 @@ def case_host_time_of_a_step_hides_behind_the_kernel():
             runner.step()
         host_paced = runner.sim.timer_stop() / steps * 1e3
         runner.finish()
+        runner.exchange.set_pacing(psim.EXCHANGE_PIPELINED)
+        for _ in range(30):
+            runner.step()
+        runner.sim.timer_start()                         # (no finish: the pipeline stays full)
+        for _ in range(steps):
+            runner.step()
+        pipelined = runner.sim.timer_stop() / steps * 1e3
+        runner.finish()
     finally:
         runner.close()
-    print(f"exchanged step {exchanged:.1f} us (host-paced {host_paced:.1f} us), "
-          f"the same kernel from a host list {kernel:.1f} us")
+    print(f"exchanged step {exchanged:.1f} us (host-paced {host_paced:.1f} us, pipelined "
+          f"{pipelined:.1f} us), the same kernel from a host list {kernel:.1f} us")
     assert exchanged < 1.3 * kernel + 8.0
     assert host_paced < 1.3 * kernel + 8.0
+    assert pipelined < 1.3 * kernel + 8.0
 
 
 
@@ -180,7 +189,7 @@ def case_three_thousand_small_steps_reuse_the_ring_correctly():
     try:
         for t in range(steps):
             if t % 500 == 0:
-                runner.exchange.set_pacing((t // 500) % 2)
+                runner.exchange.set_pacing((t // 500) % 3)
             runner.step()
         runner.finish()
         got = runner.sim.download_aos()
@@ -196,8 +205,57 @@ def case_unknown_pacing_is_rejected():
     with psim.HipParticleSimulation.new_shard(1000, 0, 1000, psim.GEN_UNIFORM) as sim:
         with psim.HipAttractorExchange(sim, psim.exchange_unique_id(), 0, 1) as ex:
             with pytest.raises(psim.PsimError) as e:
-                ex.set_pacing(2)
+                ex.set_pacing(3)
             assert e.value.code == 1
+
+
+def case_pipelined_steps_equal_the_oracle_1():
+    one_rank_steps_equal_the_oracle(1, pacing="pipelined")
+
+
+def case_pipelined_steps_equal_the_oracle_40():
+    one_rank_steps_equal_the_oracle(40, pacing="pipelined")     # the ring goes round
+
+
+def case_with_a_timeout_set_pipelined_steps_equal_the_oracle_40():
+    one_rank_steps_equal_the_oracle(40, pacing="pipelined", timeout_ms=20_000)
+
+
+def case_pipelined_the_handle_is_one_step_behind_until_sync():
+    """Pipelined pacing enqueues a step's kernel one call late: after k calls the handle holds
+    k - 1 steps; psim_exchange_sync (and last_list, and a change of pacing) applies the last."""
+    n = 50_021
+    params = T.bench_params(gravity=0.5, is_mouse_dragging=0)
+    runner = par.NativeMultiAttractorRunner(n, 0, 1, 0, params, psim.exchange_unique_id(),
+                                            force=60.0, radius=30.0, pacing="pipelined")
+
+    def oracle_after(steps):
+        want = T.oracle_gen_uniform_aos(0, n)
+        for t in range(steps):
+            want = T.oracle_update_aos(want, params, 1,
+                                       par.attractors_at(t, 1, force=60.0, radius=30.0))
+        return want
+
+    try:
+        for _ in range(3):
+            runner.step()
+        runner.sim.sync()                                # the handle's own sync: not the exchange's
+        T.assert_particles_equal(runner.sim.download_aos(), oracle_after(2), "three calls, two steps")
+        runner.finish()                                  # psim_exchange_sync applies the third
+        T.assert_particles_equal(runner.sim.download_aos(), oracle_after(3), "after the sync")
+        runner.finish()                                  # and nothing twice
+        T.assert_particles_equal(runner.sim.download_aos(), oracle_after(3), "a second sync")
+        runner.step()
+        runner.exchange.set_pacing(psim.EXCHANGE_DEVICE_PACED)   # leaving the mode applies it too
+        runner.sim.sync()
+        T.assert_particles_equal(runner.sim.download_aos(), oracle_after(4), "after the change")
+        runner.exchange.set_pacing(psim.EXCHANGE_PIPELINED)
+        runner.step()
+        last = runner.exchange.last_list()               # waits for -- and applies -- the step
+        assert last.tobytes() == par.attractors_at(4, 1, force=60.0, radius=30.0).tobytes()
+        T.assert_particles_equal(runner.sim.download_aos(), oracle_after(5), "after last_list")
+    finally:
+        runner.close()
 
 
 CASES = sorted(name for name in globals() if name.startswith("case_"))

@@ -8,7 +8,7 @@
  * compares with the CPU oracle's.
  *
  * usage: exchange_loop <rank> <world> <device> <particles_per_rank> <steps> <id_file>
- *                      [host|device] [key=value ...]
+ *                      [host|device|pipelined] [key=value ...]
  *   force=F radius=R   every attractor's force and radius (default 40, 25)
  *   timeout_ms=N       psim_exchange_set_timeout: give up instead of hanging when a rank has gone
  *   nap_us=N           the host sleeps N microseconds per step (a frame loop with other work)
@@ -70,16 +70,17 @@ static psim_attractor attractor_at(int rank, int t)
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s rank world device particles steps id_file [host|device] "
+        fprintf(stderr, "usage: %s rank world device particles steps id_file [host|device|pipelined] "
                         "[force=F] [radius=R] [timeout_ms=N] [nap_us=N] [die_after=K]\n", argv[0]);
         return 2;
     }
     unsigned timeout_ms = 0;
-    int die_after = -1, host_paced = 0;
+    int die_after = -1, pacing = PSIM_EXCHANGE_DEVICE_PACED;
     unsigned nap_us = 0;
     for (int k = 7; k < argc; ++k) {
-        if (strcmp(argv[k], "host") == 0) host_paced = 1;
-        else if (strcmp(argv[k], "device") == 0) host_paced = 0;
+        if (strcmp(argv[k], "host") == 0) pacing = PSIM_EXCHANGE_HOST_PACED;
+        else if (strcmp(argv[k], "device") == 0) pacing = PSIM_EXCHANGE_DEVICE_PACED;
+        else if (strcmp(argv[k], "pipelined") == 0) pacing = PSIM_EXCHANGE_PIPELINED;
         else if (sscanf(argv[k], "force=%f", &g_force) == 1) {}
         else if (sscanf(argv[k], "radius=%f", &g_radius) == 1) {}
         else if (sscanf(argv[k], "timeout_ms=%u", &timeout_ms) == 1) {}
@@ -101,7 +102,7 @@ int main(int argc, char **argv)
     CHECK(psim_exchange_rendezvous_file(argv[6], rank, id, 60000));
     CHECK(psim_exchange_create(&x, h, id, rank, world));
     g_exchange = x;
-    if (host_paced) CHECK(psim_exchange_set_pacing(x, PSIM_EXCHANGE_HOST_PACED));
+    CHECK(psim_exchange_set_pacing(x, pacing));
     if (timeout_ms) CHECK(psim_exchange_set_timeout(x, timeout_ms));
 
     psim_sim_params p = {0.016f, 0.25f, 0u, 5.0f, 10.0f, 0u, 0.99f, 50.0f, {0.0f, 0.0f, 0.0f}, 0u};

@@ -103,7 +103,7 @@ def test_one_rank_under_the_launcher_uses_rccl():
     assert out["sustained"]["value"] > 0          # its reduction over the ranks ran on RCCL too
 
 
-@pytest.mark.parametrize("pacing", ["host", "device"])
+@pytest.mark.parametrize("pacing", ["host", "device", "pipelined"])
 def test_multi_workload_line(pacing):
     out = run_bench("--workload", "multi", "--pacing", pacing, "--no-cpu-baseline")
     assert out["n_gpus"] == 1 and "cpu_baseline" not in out
@@ -195,6 +195,7 @@ def test_multi_gpu_exchange_check_rehearsal():
     assert "error" not in check, check
     assert check["lists_match_closed_form"] is True
     assert check["us_per_step_device"] > 0 and check["us_per_step_kernel_only"] > 0
+    assert check["us_per_step_device_host_paced"] > 0 and check["us_per_step_device_pipelined"] > 0
     assert out["n_gpus"] == 2 and out["value"] > 0
 
 
@@ -298,7 +299,7 @@ def test_billion_particle_configuration_line_at_four_and_eight_ranks(world):
     assert "no data-path collective" in out["config"]["sharding"]
 
 
-@pytest.mark.parametrize("world,pacing", [(4, "host"), (8, "host"), (8, "device")])
+@pytest.mark.parametrize("world,pacing", [(4, "host"), (8, "host"), (8, "device"), (8, "pipelined")])
 def test_multi_attractor_configuration_line_at_four_and_eight_ranks(world, pacing):
     """--config 5 at its own per-GPU size (6.25 M particles) on 4 and 8 ranks: every rank
     steps its shard through psim_exchange_step."""

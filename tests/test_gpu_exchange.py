@@ -33,10 +33,14 @@ CASES = [
     "case_one_rank_steps_equal_the_oracle_40",
     "case_one_rank_steps_equal_the_oracle_7",
     "case_pacing_switched_every_5_steps_equals_the_oracle",
+    "case_pipelined_steps_equal_the_oracle_1",
+    "case_pipelined_steps_equal_the_oracle_40",
+    "case_pipelined_the_handle_is_one_step_behind_until_sync",
     "case_three_thousand_small_steps_reuse_the_ring_correctly",
     "case_unknown_pacing_is_rejected",
     "case_with_a_timeout_set_device_paced_steps_equal_the_oracle_40",
     "case_with_a_timeout_set_host_paced_steps_equal_the_oracle_40",
+    "case_with_a_timeout_set_pipelined_steps_equal_the_oracle_40",
     "case_with_a_timeout_set_the_pacing_may_still_change",
 ]
 
@@ -132,7 +136,8 @@ C_HOST_PARAMS = dict(delta_time=0.016, gravity=0.25, color_mode=0, mouse_force=5
 
 @pytest.mark.parametrize("world,pacing,timeout_ms", [(2, "device", 0), (3, "device", 0),
                                                      (3, "host", 0), (3, "device", 20000),
-                                                     (3, "host", 20000)])
+                                                     (3, "host", 20000), (2, "pipelined", 0),
+                                                     (3, "pipelined", 0), (3, "pipelined", 20000)])
 def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world, pacing, timeout_ms):
     """The exchange's logic for a world larger than one -- every rank's place in the receive
     lists, the ring, the list length the kernel gets, shards of one global array, ranks that
@@ -153,7 +158,7 @@ def test_several_ranks_on_one_gpu_through_a_test_double(tmp_path, world, pacing,
         assert outs[r] == T.oracle_checksum_soa(T.aos_to_soa(want)), f"rank {r} of {world}"
 
 
-@pytest.mark.parametrize("pacing", ["host", "device"])
+@pytest.mark.parametrize("pacing", ["host", "device", "pipelined"])
 def test_an_all_gather_kernel_as_large_as_rccls_changes_no_result(tmp_path, pacing):
     """The test double with its all-gather kernel given the resource footprint of RCCL's own
     device kernel (37 664 B of LDS, 248 vector registers, 512 threads: a workgroup that waits
@@ -171,12 +176,12 @@ def test_an_all_gather_kernel_as_large_as_rccls_changes_no_result(tmp_path, paci
 
 
 def test_ranks_may_pace_themselves_differently(tmp_path):
-    """The pacing is each rank's own business: rank 0 host-paced, rank 1 device-paced, rank 2
+    """The pacing is each rank's own business: rank 0 host-paced, rank 1 pipelined, rank 2
     device-paced with a host that has other work per step (so it never runs ahead)."""
     world, n, steps = 3, 50_003, 20
     cpp_dir = build_c_hosts()
     env = dict(os.environ, PSIM_RCCL_LIBRARY=os.path.join(cpp_dir, "libfake_rccl.so"))
-    how = {0: ("host",), 1: ("device",), 2: ("device", "nap_us=200")}
+    how = {0: ("host",), 1: ("pipelined",), 2: ("device", "nap_us=200")}
     procs = {r: subprocess.Popen([os.path.join(cpp_dir, "exchange_loop"), str(r), str(world), "0",
                                   str(n), str(steps), str(tmp_path / "id"), *how[r]], env=env,
                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -190,7 +195,7 @@ def test_ranks_may_pace_themselves_differently(tmp_path):
         assert outs[r] == T.oracle_checksum_soa(T.aos_to_soa(want)), f"rank {r}"
 
 
-@pytest.mark.parametrize("pacing", ["host", "device"])
+@pytest.mark.parametrize("pacing", ["host", "device", "pipelined"])
 def test_fifty_million_particles_over_eight_ranks_with_eight_attractors(tmp_path, pacing):
     """The 50 M-particle configuration in its own shape -- 8 ranks of 6.25 M particles, one
     moving attractor each with r = 10 and f = 5, all-gathered every step -- with the 8 rank
@@ -213,6 +218,7 @@ def test_fifty_million_particles_over_eight_ranks_with_eight_attractors(tmp_path
     ("host", 30, "psim_exchange_step"),      # the gather of the step after the rank left
     ("device", 30, "psim_exchange_step"),    # 16 steps later: the gather that used the list before
     ("device", 12, "psim_exchange_sync"),    # the run ends first: the wait at its end
+    ("pipelined", 30, "psim_exchange_step"), # one call later than host-paced: the gather before
 ])
 def test_a_rank_that_has_gone_is_an_error_not_a_hang(tmp_path, pacing, steps, where):
     """Three ranks; rank 2 leaves after 5 steps, as a crashed process would.  With
