@@ -300,7 +300,8 @@ public:
     {
         check(psim_exchange_step(x_, &params, &mine));
     }
-    // PSIM_EXCHANGE_DEVICE_PACED (default) or PSIM_EXCHANGE_HOST_PACED
+    // PSIM_EXCHANGE_DEVICE_PACED (default), PSIM_EXCHANGE_HOST_PACED or PSIM_EXCHANGE_PIPELINED
+    // (the simulation is then one step behind until sync())
     void set_pacing(int pacing) { check(psim_exchange_set_pacing(x_, pacing)); }
     // 0 (default): wait for ever; otherwise host-side waits give up after that long
     void set_timeout(uint32_t timeout_ms) { check(psim_exchange_set_timeout(x_, timeout_ms)); }

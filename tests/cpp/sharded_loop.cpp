@@ -1,6 +1,6 @@
 // sharded_loop.cpp -- one rank of a headless, sharded run through the C++ mirror
 // (include/psim.hpp): a shard of a larger set stepped through the attractor exchange
-// (psim::HipAttractorExchange, both pacings), through the list step that allocates nothing,
+// (psim::HipAttractorExchange, all three pacings), through the list step that allocates nothing,
 // a detour through a checkpoint written in the sharded way (begin / save / commit), and the
 // occupancy and device-count queries.  It records every step it took -- the parameters and the
 // attractor list that applied -- so the test-suite can replay the run through the CPU oracle.
@@ -63,8 +63,9 @@ int main(int argc, char **argv)
             psim::HipAttractorExchange exchange(sim, psim::HipAttractorExchange::unique_id(), 0, 1);
             if (exchange.world() != 1 || exchange.rank() != 0) return 6;
             for (int t = 0; t < steps; ++t) {
-                if (t == steps / 3) exchange.set_pacing(PSIM_EXCHANGE_HOST_PACED);
-                if (t == 2 * steps / 3) exchange.set_pacing(PSIM_EXCHANGE_DEVICE_PACED);
+                if (t == steps / 4) exchange.set_pacing(PSIM_EXCHANGE_HOST_PACED);
+                if (t == steps / 2) exchange.set_pacing(PSIM_EXCHANGE_PIPELINED);   // one call late
+                if (t == 3 * steps / 4) exchange.set_pacing(PSIM_EXCHANGE_DEVICE_PACED);
                 p.delta_time = 0.016f + 0.001f * static_cast<float>(t % 5);
                 p.color_mode = static_cast<uint32_t>(t % 3);
                 const psim::Attractor mine = attractor_at(t, 0);

@@ -1,5 +1,5 @@
 """The headless C++ rank (tests/cpp/sharded_loop.cpp): one shard of a larger set driven through
-the C++ mirror of include/psim.hpp -- the attractor exchange in both pacings, the list step that
+the C++ mirror of include/psim.hpp -- the attractor exchange in all three pacings, the list step that
 allocates nothing, the sharded way of writing a checkpoint, the occupancy and device-count
 queries.  Its recorded steps are replayed through the CPU oracle; the particles must agree bit
 for bit.  The program maps RCCL and runs as a process of its own (no torch in it)."""
