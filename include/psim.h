@@ -615,7 +615,8 @@ int psim_exchange_set_pacing(psim_exchange *x, int pacing);
  * processes needs to be able to report instead.  Each rank sets its own timeout. */
 int psim_exchange_set_timeout(psim_exchange *x, uint32_t timeout_ms);
 
-/* Waits for everything the exchange and its handle have enqueued. */
+/* Enqueues the kernel of a step that pipelined pacing still holds back, then waits for
+ * everything the exchange and its handle have enqueued. */
 int psim_exchange_sync(psim_exchange *x);
 
 /* The `world` records the most recent step applied, in rank order, into host memory (waits
